@@ -1,0 +1,160 @@
+/*
+ * sd_engine.h -- C-ABI of the MI355X-native Stable Diffusion denoise engine (libsd_engine.so).
+ *
+ * The reference (GrafikXxxxxxxYyyyyyyyyyy/StableDiffusion) has no FFI / plugin layer of its own: its
+ * hot path is two Python object slots, `SDModelWrapper.base` (UNet2DConditionModel) and
+ * `SDModelWrapper.vae` (AutoencoderKL), filled at /root/reference/models/stable_diffusion.py:110-123
+ * and called at /root/reference/pipelines/sd_unified_pipeline.py:475-482 (UNet forward) and
+ * :523 (VAE decode), :1027-1032 (VAE encode).  The entry points below are what a ctypes binding
+ * for those slots binds (INTEGRATION.md shows the stub); each one names the reference interface
+ * it replaces.
+ *
+ * Conventions
+ *   - plain C: opaque handles, plain pointers and sizes, int return codes (0 = ok); no torch types.
+ *   - every tensor buffer is DEVICE memory owned by the caller; the library owns only its packed
+ *     weights and a workspace arena sized on first use of a shape.
+ *   - boundary tensors are NCHW fp16, contiguous -- the layout of the reference's tensors; the
+ *     engine runs NHWC internally.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and never synchronise.
+ *   - errors: non-zero code + thread-local message from sd_last_error(); the Python shim raises
+ *     RuntimeError, matching the reference's plain-exception convention
+ *     (sd_unified_pipeline.py:302-306).
+ *   - single caller thread per handle (the reference's handler is synchronous, rp_handler.py:44-63).
+ */
+#ifndef SD_ENGINE_H
+#define SD_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_OK 0
+#define SD_ERR_INVALID 1   /* bad argument / unknown key / shape mismatch */
+#define SD_ERR_STATE 2     /* call order violated (e.g. forward before finalize) */
+#define SD_ERR_HIP 3       /* HIP runtime error */
+#define SD_ERR_UNSUPPORTED 4
+
+#define SD_DTYPE_F16 0
+#define SD_DTYPE_F32 1
+
+#define SD_MAX_BLOCKS 4
+
+/* UNet2DConditionModel hyper-parameters; field meaning = diffusers config fields as derived at
+ * /root/reference/scripts/convert_from_A1111.py:175-189.  block type 1 = CrossAttn*Block2D, 0 = plain. */
+typedef struct sd_unet_config {
+    int32_t in_channels;
+    int32_t out_channels;
+    int32_t num_blocks;
+    int32_t block_out_channels[SD_MAX_BLOCKS];
+    int32_t down_block_has_attn[SD_MAX_BLOCKS];
+    int32_t up_block_has_attn[SD_MAX_BLOCKS];
+    int32_t num_heads[SD_MAX_BLOCKS];              /* per down block; reversed for up blocks */
+    int32_t transformer_layers[SD_MAX_BLOCKS];     /* per down block; reversed for up blocks */
+    int32_t layers_per_block;
+    int32_t cross_attention_dim;
+    int32_t use_linear_projection;
+    int32_t norm_num_groups;
+    float   norm_eps;
+    int32_t flip_sin_to_cos;
+    float   freq_shift;
+    int32_t addition_time_embed_dim;               /* 0 = no text_time conditioning (SD1.5) */
+    int32_t projection_class_embeddings_input_dim; /* SDXL: 2816 */
+} sd_unet_config;
+
+/* AutoencoderKL hyper-parameters (convert_from_A1111.py:490-511). */
+typedef struct sd_vae_config {
+    int32_t in_channels;      /* 3 */
+    int32_t out_channels;     /* 3 */
+    int32_t latent_channels;  /* 4 */
+    int32_t num_blocks;
+    int32_t block_out_channels[SD_MAX_BLOCKS];
+    int32_t layers_per_block;
+    int32_t norm_num_groups;
+} sd_vae_config;
+
+typedef struct sd_unet sd_unet;
+typedef struct sd_vae sd_vae;
+
+/* -- library ------------------------------------------------------------------------------- */
+const char* sd_last_error(void);
+int sd_engine_version(void);
+/* Name of the code object's ISA target ("gfx950"). */
+const char* sd_engine_arch(void);
+
+/* -- UNet: replaces the object in SDModelWrapper.base (stable_diffusion.py:117-123) ---------- */
+int sd_unet_create(const sd_unet_config* cfg, sd_unet** out);
+int sd_unet_destroy(sd_unet* u);
+/* Number of weight tensors the model expects / name and rank+shape of the i-th one, in
+ * diffusers state-dict naming (convert_from_A1111.py:240-485). */
+int sd_unet_num_weights(const sd_unet* u);
+int sd_unet_weight_info(const sd_unet* u, int index, const char** key, int64_t* shape4, int* ndim);
+/* Hand one tensor over (host or device pointer, contiguous, PyTorch layout:
+ * conv [Cout,Cin,KH,KW], linear [out,in], vectors [C]).  The library copies + repacks; the
+ * caller's buffer can be freed on return.  Replaces state_dict loading done by
+ * UNet2DConditionModel.from_pretrained (stable_diffusion.py:117-123). */
+int sd_unet_set_weight(sd_unet* u, const char* diffusers_key, const void* data,
+                       const int64_t* shape, int ndim, int dtype);
+/* All weights present -> pre-pack (fused qkv, GEGLU interleave, time-emb projection stack). */
+int sd_unet_finalize(sd_unet* u);
+/* UNet2DConditionModel.forward as called at sd_unified_pipeline.py:475-482.
+ *   sample     [B,Cin,H,W] f16      latent_model_input
+ *   timesteps  [B] f32 (device)     `t` broadcast to the batch
+ *   ehs        [B,L,D] f16          prompt_embeds
+ *   add_text   [B,P] f16 or NULL    added_cond_kwargs["text_embeds"]  (SDXL, :430-433)
+ *   add_time_ids [B,6] f32 or NULL  added_cond_kwargs["time_ids"]
+ *   out        [B,Cout,H,W] f16     noise_pred
+ */
+int sd_unet_forward(sd_unet* u, const void* sample, const float* timesteps, const void* ehs,
+                    int ehs_len, const void* add_text, const float* add_time_ids, void* out,
+                    int B, int H, int W, void* stream);
+/* Bytes of device memory held (packed weights, workspace). */
+int sd_unet_memory(const sd_unet* u, int64_t* weight_bytes, int64_t* workspace_bytes);
+
+/* -- VAE: replaces the object in SDModelWrapper.vae (stable_diffusion.py:110-116) ------------ */
+int sd_vae_create(const sd_vae_config* cfg, sd_vae** out);
+int sd_vae_destroy(sd_vae* v);
+int sd_vae_num_weights(const sd_vae* v);
+int sd_vae_weight_info(const sd_vae* v, int index, const char** key, int64_t* shape4, int* ndim);
+int sd_vae_set_weight(sd_vae* v, const char* diffusers_key, const void* data,
+                      const int64_t* shape, int ndim, int dtype);
+int sd_vae_finalize(sd_vae* v);
+/* AutoencoderKL.decode(z)[0] (sd_unified_pipeline.py:523): z [B,4,h,w] f16 -> img [B,3,8h,8w] f16. */
+int sd_vae_decode(sd_vae* v, const void* z, void* img, int B, int h, int w, void* stream);
+/* AutoencoderKL.encode(x) up to the moments (sd_unified_pipeline.py:1027-1032):
+ * img [B,3,H,W] f16 -> moments [B,8,H/8,W/8] f16 (mean | logvar); sampling stays host code. */
+int sd_vae_encode(sd_vae* v, const void* img, void* moments, int B, int H, int W, void* stream);
+int sd_vae_memory(const sd_vae* v, int64_t* weight_bytes, int64_t* workspace_bytes);
+
+/* -- denoise-step glue (sd_unified_pipeline.py:467-469, :484-489) ---------------------------- */
+/* latent_model_input = cat([latents]*2) * in_scale   (in_scale = 1 for DDIM / DPM++) */
+int sd_cfg_duplicate(const void* latents, void* out2b, int64_t n_per_batch, int B, float in_scale,
+                     void* stream);
+/* noise = u + g (t - u);  x <- c_x * x + c_eps * noise   (DDIM eta=0 written as an affine update;
+ * coefficients computed on the host by the scheduler).  noise_pred_2b = [uncond ; text]. */
+int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float guidance_scale,
+                     float c_x, float c_eps, void* stream);
+
+/* -- single operators, exported for the parity tests (tests/test_ops_gpu.py) ----------------- */
+/* Implicit-GEMM convolution / linear on NHWC f16:
+ *   y[n,oh,ow,co] = bias[co] + rowadd[n,co] + res[n,oh,ow,co]
+ *                 + sum_{kh,kw,ci} x[n, (oh*stride+kh-pad)>>up, (ow*stride+kw-pad)>>up, ci] * w[co,kh,kw,ci]
+ * w is PyTorch [Cout,Cin,KH,KW] (f16, device); packed internally per call (test path only). */
+int sd_op_conv2d(const void* x_nhwc, const void* w_oihw, const void* bias, const void* rowadd,
+                 const void* res_nhwc, void* y_nhwc, int N, int H, int W, int Cin, int Cout,
+                 int ksize, int stride, int upsample2x, int geglu, void* stream);
+/* GroupNorm (+ optional SiLU) on NHWC f16, fp32 statistics. */
+int sd_op_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
+                    int N, int HW, int C, int groups, float eps, int silu, void* stream);
+/* LayerNorm over the last dim of [rows, C] f16. */
+int sd_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C,
+                    float eps, void* stream);
+/* softmax(q k^T / sqrt(d)) v.  q [B,Tq,heads*d] (row stride ldq), k/v [B,Tk,heads*d], out like q. */
+int sd_op_attention(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk,
+                    int heads, int d, int ldq, int ldk, int ldv, int ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_ENGINE_H */

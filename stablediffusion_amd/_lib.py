@@ -1,0 +1,121 @@
+"""ctypes binding of libsd_engine.so (the C-ABI in include/sd_engine.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails the shim
+raises -- the product path never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsd_engine.so")
+
+SD_MAX_BLOCKS = 4
+SD_DTYPE_F16 = 0
+SD_DTYPE_F32 = 1
+
+
+class SdUNetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32),
+        ("out_channels", C.c_int32),
+        ("num_blocks", C.c_int32),
+        ("block_out_channels", C.c_int32 * SD_MAX_BLOCKS),
+        ("down_block_has_attn", C.c_int32 * SD_MAX_BLOCKS),
+        ("up_block_has_attn", C.c_int32 * SD_MAX_BLOCKS),
+        ("num_heads", C.c_int32 * SD_MAX_BLOCKS),
+        ("transformer_layers", C.c_int32 * SD_MAX_BLOCKS),
+        ("layers_per_block", C.c_int32),
+        ("cross_attention_dim", C.c_int32),
+        ("use_linear_projection", C.c_int32),
+        ("norm_num_groups", C.c_int32),
+        ("norm_eps", C.c_float),
+        ("flip_sin_to_cos", C.c_int32),
+        ("freq_shift", C.c_float),
+        ("addition_time_embed_dim", C.c_int32),
+        ("projection_class_embeddings_input_dim", C.c_int32),
+    ]
+
+
+class SdVAEConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32),
+        ("out_channels", C.c_int32),
+        ("latent_channels", C.c_int32),
+        ("num_blocks", C.c_int32),
+        ("block_out_channels", C.c_int32 * SD_MAX_BLOCKS),
+        ("layers_per_block", C.c_int32),
+        ("norm_num_groups", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/sd_engine.h declares
+_P = C.c_void_p
+_I = C.c_int
+_I64 = C.c_int64
+_F = C.c_float
+SIGNATURES = {
+    "sd_last_error": (C.c_char_p, []),
+    "sd_engine_version": (_I, []),
+    "sd_engine_arch": (C.c_char_p, []),
+    "sd_unet_create": (_I, [C.POINTER(SdUNetConfig), C.POINTER(_P)]),
+    "sd_unet_destroy": (_I, [_P]),
+    "sd_unet_num_weights": (_I, [_P]),
+    "sd_unet_weight_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I64), C.POINTER(_I)]),
+    "sd_unet_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _I]),
+    "sd_unet_finalize": (_I, [_P]),
+    "sd_unet_forward": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "sd_unet_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "sd_vae_create": (_I, [C.POINTER(SdVAEConfig), C.POINTER(_P)]),
+    "sd_vae_destroy": (_I, [_P]),
+    "sd_vae_num_weights": (_I, [_P]),
+    "sd_vae_weight_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I64), C.POINTER(_I)]),
+    "sd_vae_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _I]),
+    "sd_vae_finalize": (_I, [_P]),
+    "sd_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sd_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sd_vae_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "sd_cfg_duplicate": (_I, [_P, _P, _I64, _I, _F, _P]),
+    "sd_cfg_ddim_step": (_I, [_P, _P, _I64, _F, _F, _F, _P]),
+    "sd_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sd_op_groupnorm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "sd_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "sd_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsd_engine.so; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} not found: build it with `python -m stablediffusion_amd.build` "
+            "(hipcc --offload-arch=gfx950). The HIP engine is mandatory; there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().sd_last_error()
+        raise EngineError(f"{what}: error {rc}: {msg.decode() if msg else '?'}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise EngineError("no HIP device visible: the gfx950 engine cannot run (and nothing else will run in its place)")

@@ -1,0 +1,228 @@
+// extern "C" surface of libsd_engine.so -- see include/sd_engine.h for the contract and for the
+// reference interfaces (file:line) each entry point replaces.
+#include <new>
+
+#include "model.h"
+
+using namespace sd;
+
+struct sd_unet { UNet impl; explicit sd_unet(const sd_unet_config& c) : impl(c) {} };
+struct sd_vae { VAE impl; explicit sd_vae(const sd_vae_config& c) : impl(c) {} };
+
+namespace {
+
+int weight_info(const WeightStore& ws, int index, const char** key, int64_t* shape4, int* ndim) {
+    if (index < 0 || index >= (int)ws.order.size()) { set_error("weight index out of range"); return SD_ERR_INVALID; }
+    const std::string& k = ws.order[(size_t)index];
+    const RawTensor& t = ws.tensors.at(k);
+    *key = k.c_str();
+    *ndim = (int)t.shape.size();
+    for (int i = 0; i < 4; ++i) shape4[i] = i < *ndim ? t.shape[(size_t)i] : 1;
+    return SD_OK;
+}
+
+bool bad_cfg(const sd_unet_config* c) {
+    if (!c || c->num_blocks < 1 || c->num_blocks > SD_MAX_BLOCKS) return true;
+    for (int i = 0; i < c->num_blocks; ++i) {
+        if (c->block_out_channels[i] % 64 != 0 || c->block_out_channels[i] % c->norm_num_groups != 0) return true;
+        if (c->num_heads[i] <= 0 || c->block_out_channels[i] % c->num_heads[i] != 0) return true;
+        if ((c->down_block_has_attn[i] || c->up_block_has_attn[c->num_blocks - 1 - i]) &&
+            !attention_supported(c->block_out_channels[i] / c->num_heads[i])) return true;
+    }
+    return c->cross_attention_dim % 64 != 0 || c->in_channels <= 0 || c->in_channels > 16;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sd_last_error(void) { return sd::last_error().c_str(); }
+int sd_engine_version(void) { return 1; }
+const char* sd_engine_arch(void) { return "gfx950"; }
+
+// ------------------------------------------------------------------------------------------- UNet
+int sd_unet_create(const sd_unet_config* cfg, sd_unet** out) {
+    if (!out) { set_error("null out"); return SD_ERR_INVALID; }
+    if (bad_cfg(cfg)) {
+        set_error("sd_unet_create: unsupported config (channels must be multiples of 64 and of the group "
+                  "count, head dims in {32,40,64,80,128,160}, cross_attention_dim % 64 == 0)");
+        return SD_ERR_UNSUPPORTED;
+    }
+    *out = new (std::nothrow) sd_unet(*cfg);
+    if (!*out) { set_error("out of host memory"); return SD_ERR_INVALID; }
+    return SD_OK;
+}
+int sd_unet_destroy(sd_unet* u) { delete u; return SD_OK; }
+int sd_unet_num_weights(const sd_unet* u) { return u ? (int)u->impl.ws.order.size() : 0; }
+int sd_unet_weight_info(const sd_unet* u, int index, const char** key, int64_t* shape4, int* ndim) {
+    if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
+    return weight_info(u->impl.ws, index, key, shape4, ndim);
+}
+int sd_unet_set_weight(sd_unet* u, const char* key, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!u || !key || !data || !shape) { set_error("null argument"); return SD_ERR_INVALID; }
+    if (u->impl.finalized) { set_error("set_weight after finalize"); return SD_ERR_STATE; }
+    return u->impl.ws.set(key, data, shape, ndim, dtype);
+}
+int sd_unet_finalize(sd_unet* u) {
+    if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
+    return u->impl.finalize();
+}
+int sd_unet_forward(sd_unet* u, const void* sample, const float* timesteps, const void* ehs, int ehs_len,
+                    const void* add_text, const float* add_time_ids, void* out, int B, int H, int W,
+                    void* stream) {
+    if (!u || !sample || !timesteps || !ehs || !out) { set_error("null argument"); return SD_ERR_INVALID; }
+    return u->impl.forward(static_cast<const half_t*>(sample), timesteps, static_cast<const half_t*>(ehs),
+                           ehs_len, static_cast<const half_t*>(add_text), add_time_ids,
+                           static_cast<half_t*>(out), B, H, W, static_cast<hipStream_t>(stream));
+}
+int sd_unet_memory(const sd_unet* u, int64_t* weight_bytes, int64_t* workspace_bytes) {
+    if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
+    if (weight_bytes) *weight_bytes = u->impl.ws.packed_bytes();
+    if (workspace_bytes) *workspace_bytes = (int64_t)u->impl.arena.capacity();
+    return SD_OK;
+}
+
+// -------------------------------------------------------------------------------------------- VAE
+int sd_vae_create(const sd_vae_config* cfg, sd_vae** out) {
+    if (!out || !cfg) { set_error("null argument"); return SD_ERR_INVALID; }
+    bool bad = cfg->num_blocks < 1 || cfg->num_blocks > SD_MAX_BLOCKS || cfg->latent_channels > 8;
+    for (int i = 0; !bad && i < cfg->num_blocks; ++i)
+        bad = cfg->block_out_channels[i] % 64 != 0;
+    if (!bad) bad = !attention_supported(cfg->block_out_channels[cfg->num_blocks - 1]);
+    if (bad) { set_error("sd_vae_create: unsupported config"); return SD_ERR_UNSUPPORTED; }
+    *out = new (std::nothrow) sd_vae(*cfg);
+    if (!*out) { set_error("out of host memory"); return SD_ERR_INVALID; }
+    return SD_OK;
+}
+int sd_vae_destroy(sd_vae* v) { delete v; return SD_OK; }
+int sd_vae_num_weights(const sd_vae* v) { return v ? (int)v->impl.ws.order.size() : 0; }
+int sd_vae_weight_info(const sd_vae* v, int index, const char** key, int64_t* shape4, int* ndim) {
+    if (!v) { set_error("null handle"); return SD_ERR_INVALID; }
+    return weight_info(v->impl.ws, index, key, shape4, ndim);
+}
+int sd_vae_set_weight(sd_vae* v, const char* key, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!v || !key || !data || !shape) { set_error("null argument"); return SD_ERR_INVALID; }
+    if (v->impl.finalized) { set_error("set_weight after finalize"); return SD_ERR_STATE; }
+    return v->impl.ws.set(key, data, shape, ndim, dtype);
+}
+int sd_vae_finalize(sd_vae* v) {
+    if (!v) { set_error("null handle"); return SD_ERR_INVALID; }
+    return v->impl.finalize();
+}
+int sd_vae_decode(sd_vae* v, const void* z, void* img, int B, int h, int w, void* stream) {
+    if (!v || !z || !img) { set_error("null argument"); return SD_ERR_INVALID; }
+    return v->impl.decode(static_cast<const half_t*>(z), static_cast<half_t*>(img), B, h, w,
+                          static_cast<hipStream_t>(stream));
+}
+int sd_vae_encode(sd_vae* v, const void* img, void* moments, int B, int H, int W, void* stream) {
+    if (!v || !img || !moments) { set_error("null argument"); return SD_ERR_INVALID; }
+    return v->impl.encode(static_cast<const half_t*>(img), static_cast<half_t*>(moments), B, H, W,
+                          static_cast<hipStream_t>(stream));
+}
+int sd_vae_memory(const sd_vae* v, int64_t* weight_bytes, int64_t* workspace_bytes) {
+    if (!v) { set_error("null handle"); return SD_ERR_INVALID; }
+    if (weight_bytes) *weight_bytes = v->impl.ws.packed_bytes();
+    if (workspace_bytes) *workspace_bytes = (int64_t)v->impl.arena.capacity();
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------------------------- step glue
+int sd_cfg_duplicate(const void* latents, void* out2b, int64_t n_per_batch, int B, float in_scale, void* stream) {
+    if (!latents || !out2b) { set_error("null argument"); return SD_ERR_INVALID; }
+    return launch_cfg_duplicate(static_cast<const half_t*>(latents), static_cast<half_t*>(out2b),
+                                (long)n_per_batch * B, in_scale, static_cast<hipStream_t>(stream));
+}
+int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float guidance_scale, float c_x,
+                     float c_eps, void* stream) {
+    if (!noise_pred_2b || !latents) { set_error("null argument"); return SD_ERR_INVALID; }
+    return launch_cfg_ddim(static_cast<const half_t*>(noise_pred_2b), static_cast<half_t*>(latents), (long)n,
+                           guidance_scale, c_x, c_eps, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------- single-operator entries
+// Test-path only: packs the weight on every call (allocation + sync); never used by the models.
+int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
+                 void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int upsample2x,
+                 int geglu, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long K = (long)ksize * ksize * Cin;
+    if (K % 64 != 0 || Cin % 64 != 0) { set_error("sd_op_conv2d: Cin must be a multiple of 64"); return SD_ERR_INVALID; }
+    const long rows = (Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    half_t* wp = nullptr;
+    float* bp = nullptr;
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)rows * K * sizeof(half_t)));
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bp), (size_t)rows * sizeof(float)));
+    SD_HIP_CHECK(hipMemsetAsync(wp, 0, (size_t)rows * K * sizeof(half_t), s));
+    SD_HIP_CHECK(hipMemsetAsync(bp, 0, (size_t)rows * sizeof(float), s));
+    int rc = launch_pack_conv(static_cast<const half_t*>(w_oihw), wp, Cout, Cin, ksize, ksize, K, s);
+    if (!rc && bias_f32)
+        SD_HIP_CHECK(hipMemcpyAsync(bp, bias_f32, (size_t)Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!rc && geglu) {
+        // interleave hidden / gate rows per 64 exactly as WeightStore::pack_geglu does
+        half_t* wg = nullptr; float* bg = nullptr;
+        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wg), (size_t)rows * K * sizeof(half_t)));
+        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bg), (size_t)rows * sizeof(float)));
+        SD_HIP_CHECK(hipMemsetAsync(wg, 0, (size_t)rows * K * sizeof(half_t), s));
+        SD_HIP_CHECK(hipMemsetAsync(bg, 0, (size_t)rows * sizeof(float), s));
+        const long half_rows = Cout / 2;
+        for (long blk = 0; blk < half_rows / 64; ++blk) {
+            SD_HIP_CHECK(hipMemcpyAsync(wg + blk * 128 * K, wp + blk * 64 * K, (size_t)64 * K * 2, hipMemcpyDeviceToDevice, s));
+            SD_HIP_CHECK(hipMemcpyAsync(wg + (blk * 128 + 64) * K, wp + (half_rows + blk * 64) * K, (size_t)64 * K * 2, hipMemcpyDeviceToDevice, s));
+            SD_HIP_CHECK(hipMemcpyAsync(bg + blk * 128, bp + blk * 64, 64 * 4, hipMemcpyDeviceToDevice, s));
+            SD_HIP_CHECK(hipMemcpyAsync(bg + blk * 128 + 64, bp + half_rows + blk * 64, 64 * 4, hipMemcpyDeviceToDevice, s));
+        }
+        SD_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(wp); (void)hipFree(bp);
+        wp = wg; bp = bg;
+    }
+    if (!rc) {
+        IGemmParams p;
+        p.x = static_cast<const half_t*>(x); p.ldx = Cin;
+        p.w = wp; p.bias = bp;
+        p.rowadd = static_cast<const float*>(rowadd_f32); p.rowadd_ld = Cout;
+        p.res = static_cast<const half_t*>(res);
+        p.N = N; p.H = H; p.W = W; p.Cin = Cin;
+        p.KS = ksize; p.stride = stride; p.up = upsample2x; p.pad = ksize == 3 ? 1 : 0;
+        const int IH = H << upsample2x, IW = W << upsample2x;
+        p.OH = (IH + 2 * p.pad - ksize) / stride + 1;
+        p.OW = (IW + 2 * p.pad - ksize) / stride + 1;
+        p.Cout = Cout; p.M = N * p.OH * p.OW; p.K = (int)K; p.geglu = geglu;
+        const int ocols = geglu ? Cout / 2 : Cout;
+        p.ldres = ocols; p.y = static_cast<half_t*>(y); p.ldy = ocols;
+        rc = launch_igemm(p, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(wp); (void)hipFree(bp);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
+int sd_op_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int N, int HW, int C,
+                    int groups, float eps, int silu, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* scratch = nullptr;
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t)gn_scratch_floats(N, HW, C, groups) * 4));
+    int rc = launch_groupnorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),
+                              static_cast<const float*>(beta_f32), static_cast<half_t*>(y), C, N, HW, C, groups,
+                              eps, silu, scratch, s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
+int sd_op_layernorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int rows, int C, float eps,
+                    void* stream) {
+    return launch_layernorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),
+                            static_cast<const float*>(beta_f32), static_cast<half_t*>(y), C, rows, C, eps,
+                            static_cast<hipStream_t>(stream));
+}
+
+int sd_op_attention(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk, int heads, int d,
+                    int ldq, int ldk, int ldv, int ldo, void* stream) {
+    return launch_attention(static_cast<const half_t*>(q), static_cast<const half_t*>(k),
+                            static_cast<const half_t*>(v), static_cast<half_t*>(out), B, Tq, Tk, heads, d, ldq, ldk,
+                            ldv, ldo, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) denoise engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define SD_WAVE 64
+
+namespace sd {
+
+// Thread-local error string behind sd_last_error().
+void set_error(const std::string& msg);
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace sd
+
+#define SD_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            sd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));           \
+            return 3;                                                                   \
+        }                                                                               \
+    } while (0)
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+// XCD-aware, bijective block-id remap (8 XCDs, round-robin dispatch): blocks that end up on one
+// XCD get a contiguous range of tile ids so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+#endif

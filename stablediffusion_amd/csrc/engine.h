@@ -1,0 +1,107 @@
+// Host-side runtime of the denoise engine: device memory arena, packed-weight store and the
+// execution context shared by the UNet and VAE graphs.  Plain C++ + HIP runtime; no torch.
+#pragma once
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+namespace sd {
+
+// Activation view: NHWC fp16 tensor living at `p` with row (pixel) stride `ld` elements.
+struct View {
+    half_t* p = nullptr;
+    long ld = 0;
+    int C = 0;
+    View() {}
+    View(half_t* p_, long ld_, int C_) : p(p_), ld(ld_), C(C_) {}
+    View slice(int c0, int c) const { return View(p + c0, ld, c); }
+};
+
+// Bump allocator over one hipMalloc'ed slab with stack-style mark/release.  In "dry" mode no memory
+// is attached and only the peak is recorded; the real slab is sized from that.
+class Arena {
+  public:
+    ~Arena();
+    int reserve(size_t bytes);            // (re)allocate the slab if smaller than `bytes`
+    void begin(bool dry) { dry_ = dry; off_ = 0; if (dry) peak_ = 0; }
+    void* alloc(size_t bytes);
+    half_t* alloc_h(long n) { return static_cast<half_t*>(alloc((size_t)n * sizeof(half_t))); }
+    float* alloc_f(long n) { return static_cast<float*>(alloc((size_t)n * sizeof(float))); }
+    size_t mark() const { return off_; }
+    void release(size_t m) { off_ = m; }
+    size_t peak() const { return peak_; }
+    size_t capacity() const { return cap_; }
+    bool dry() const { return dry_; }
+    bool overflow() const { return overflow_; }
+
+  private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, off_ = 0, peak_ = 0;
+    bool dry_ = false, overflow_ = false;
+};
+
+struct ConvW {          // conv or linear, packed [rows_pad][K] fp16 + fp32 bias (padded)
+    half_t* w = nullptr;
+    float* bias = nullptr;
+    int cin = 0, cout = 0, ks = 1;
+    long K = 0;         // packed K (>= ks*ks*cin, multiple of 64)
+};
+struct NormW {
+    float* gamma = nullptr;
+    float* beta = nullptr;
+    int C = 0;
+};
+
+// Raw tensors handed over through sd_*_set_weight, kept on device as fp16 until finalize().
+struct RawTensor {
+    std::vector<int64_t> shape;
+    half_t* dev = nullptr;
+    long numel = 0;
+};
+
+class WeightStore {
+  public:
+    ~WeightStore();
+    void declare(const std::string& key, std::vector<int64_t> shape);
+    int set(const std::string& key, const void* data, const int64_t* shape, int ndim, int dtype);
+    bool complete(std::string* missing) const;
+    const RawTensor* raw(const std::string& key) const;
+    // packing helpers (device work on the null stream; finalize() synchronises once)
+    int pack_conv(const std::string& prefix, ConvW* out, bool has_bias = true);
+    int pack_rows(const std::vector<std::string>& weight_keys, const std::vector<std::string>& bias_keys,
+                  ConvW* out);                                  // row-concatenated linears
+    int pack_geglu(const std::string& prefix, ConvW* out);      // [8C][C] -> 64-row interleave
+    int pack_norm(const std::string& prefix, NormW* out);
+    void free_raw();
+    void* dmalloc(size_t bytes);                                // tracked device allocation
+    int64_t packed_bytes() const { return packed_bytes_; }
+
+    std::vector<std::string> order;                             // manifest order
+    std::unordered_map<std::string, RawTensor> tensors;
+
+  private:
+    int host_floats(const std::string& key, std::vector<float>* out) const;
+    std::vector<void*> owned_;
+    int64_t packed_bytes_ = 0;
+};
+
+// Execution context of one forward call.
+struct Ctx {
+    Arena* arena;
+    hipStream_t stream;
+    bool dry;
+    int err = 0;
+};
+
+// ---- op wrappers: skip the launch in dry mode, latch the first error ----
+void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride = 1, int up = 0,
+             const float* rowadd = nullptr, int rowadd_ld = 0, const View* res = nullptr, int geglu = 0,
+             int pad = -1);
+void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu);
+void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps);
+void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d);
+
+}  // namespace sd

@@ -1,0 +1,80 @@
+// Host-side launchers of the HIP kernels (definitions in *.hip).  All tensors are device memory,
+// activations are NHWC fp16 "views": a base pointer plus a row stride (`ld`, in elements) so a
+// tensor can live inside a wider buffer (zero-copy skip concatenation).
+#pragma once
+#include "common.h"
+
+namespace sd {
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution / linear (igemm.hip)
+//   y[m, co] = bias[co] + rowadd[n(m), co] + res[m, co] + sum_k A[m, k] * Wp[co, k]
+//   m = (n, oh, ow);  k = (kh, kw, ci);  A gathered on the fly from x (zero padding, stride,
+//   optional nearest-2x upsample of the input).  Wp is the packed weight [rows >= Cout][K].
+// ---------------------------------------------------------------------------------------------
+struct IGemmParams {
+    const half_t* x; long ldx;
+    const half_t* w;
+    const float* bias;
+    const float* rowadd; int rowadd_ld;
+    const half_t* res; long ldres;
+    half_t* y; long ldy;
+    int N, H, W, Cin;       // input geometry (before the optional 2x upsample)
+    int OH, OW, Cout;       // output geometry; Cout = GEMM columns (2x the stored width for GEGLU)
+    int KS, stride, pad, up;
+    int M, K;
+    int geglu;              // 1: y[m, j] = hidden_j * gelu(gate_j), weights interleaved per 64
+};
+int launch_igemm(const IGemmParams& p, hipStream_t s);
+// Rows the packed weight matrix must be padded to (zero rows), so tile loads need no masks.
+constexpr int kWeightRowPad = 256;
+
+// ---------------------------------------------------------------------------------------------
+// Normalisation (norm.hip)
+// ---------------------------------------------------------------------------------------------
+// GroupNorm over NHWC: x [N, HW, C] (ld), groups G.  `scratch` must hold gn_scratch_floats().
+long gn_scratch_floats(int N, long HW, int C, int G);
+int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float* beta,
+                     half_t* y, long ldy, int N, long HW, int C, int G, float eps, int silu,
+                     float* scratch, hipStream_t s);
+int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta,
+                     half_t* y, long ldy, long rows, int C, float eps, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Attention (attention.hip): out = softmax(q k^T / sqrt(d)) v per (batch, head)
+// ---------------------------------------------------------------------------------------------
+int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* out,
+                     int B, int Tq, int Tk, int heads, int d,
+                     long ldq, long ldk, long ldv, long ldo, hipStream_t s);
+bool attention_supported(int d);
+
+// ---------------------------------------------------------------------------------------------
+// Small / elementwise kernels (misc.hip)
+// ---------------------------------------------------------------------------------------------
+// out[b, :] = [cos(t_b f_i) | sin(t_b f_i)] (flip) or [sin | cos]; f_i = exp(-ln(1e4) i/(half-shift))
+int launch_timestep_sinusoid(const float* t, int t_stride, float* out, int count, int dim, int flip, float shift,
+                             long out_ld, hipStream_t s);
+// y[b, n] = bias[n] + sum_k act(x[b, k]) * W[n, k]  for small b (time-embedding MLPs); fp32 in/out.
+int launch_small_linear(const float* x, long ldx, const half_t* w, const float* bias, float* y,
+                        long ldy, int B, int K, int Nout, int silu_in, int silu_out, hipStream_t s);
+int launch_add_f32(float* y, const float* x, long n, hipStream_t s);
+int launch_f16_to_f32(const half_t* x, float* y, long n, hipStream_t s);
+int launch_f32_to_f16(const float* x, half_t* y, long n, hipStream_t s);
+// NCHW fp16 [N,C,H,W] -> im2col rows [N*H*W, Kpad] for a 3x3 pad-1 conv with tiny C (k=(kh,kw,c)).
+int launch_im2col_nchw3x3(const half_t* x, half_t* col, int N, int C, int H, int W, int Kpad,
+                          hipStream_t s);
+// NHWC [M, C] (ld) -> NCHW [N, C, HW]
+int launch_nhwc_to_nchw(const half_t* x, long ldx, half_t* y, int N, long HW, int C, hipStream_t s);
+// NCHW [N,C,HW] -> NHWC [M, C] (ld)
+int launch_nchw_to_nhwc(const half_t* x, half_t* y, long ldy, int N, long HW, int C, hipStream_t s);
+// Pointwise CxC conv on NCHW with tiny C (VAE post_quant_conv / quant_conv).
+int launch_pointwise_nchw(const half_t* x, const half_t* w, const float* bias, half_t* y, int N,
+                          int Cin, int Cout, long HW, hipStream_t s);
+// Weight packing: OIHW -> [O][KH][KW][I(+pad)] rows; Kpad >= KH*KW*I.
+int launch_pack_conv(const half_t* w_oihw, half_t* wp, int O, int I, int KH, int KW, long Kpad,
+                     hipStream_t s);
+int launch_cfg_duplicate(const half_t* lat, half_t* out, long n_total, float scale, hipStream_t s);
+int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx, float ce,
+                    hipStream_t s);
+
+}  // namespace sd

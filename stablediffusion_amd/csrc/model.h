@@ -1,0 +1,105 @@
+// Model graphs (UNet2DConditionModel, AutoencoderKL) assembled from the gfx950 kernels.
+#pragma once
+#include "../../include/sd_engine.h"
+#include "engine.h"
+
+namespace sd {
+
+const std::string& last_error();
+
+struct Resnet {
+    NormW n1, n2;
+    ConvW c1, c2, sc;
+    bool has_sc = false;
+    int temb_off = -1;
+    int cin = 0, cout = 0;
+};
+struct TBlock {
+    NormW ln1, ln2, ln3;
+    ConvW qkv, out1, q2, kv2, out2, ff1, ff2;
+};
+struct Xformer {
+    NormW gn;
+    ConvW pin, pout;
+    std::vector<TBlock> blocks;
+    int C = 0, heads = 1;
+};
+struct VaeAttn {
+    NormW gn;
+    ConvW qkv, out;
+    int C = 0;
+};
+
+void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
+                const float* tproj, int tproj_ld);
+void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G,
+                 const half_t* ehs, int L, int ctx_dim);
+
+struct UNet {
+    explicit UNet(const sd_unet_config& c);
+    int finalize();
+    int forward(const half_t* sample, const float* timesteps, const half_t* ehs, int L,
+                const half_t* add_text, const float* add_time_ids, half_t* out, int B, int H, int W,
+                hipStream_t stream);
+
+    sd_unet_config cfg;
+    WeightStore ws;
+    Arena arena;
+    bool finalized = false;
+    long planned_key = -1;
+
+    ConvW conv_in, conv_out, te1, te2, ae1, ae2, temb_stack;
+    NormW norm_out;
+    std::vector<std::vector<Resnet>> down_res, up_res;
+    std::vector<std::vector<Xformer>> down_att, up_att;
+    std::vector<ConvW> down_ds, up_us;
+    Resnet mid_r0, mid_r1;
+    Xformer mid_att;
+    int temb_total = 0;
+
+  private:
+    int pack_resnet(const std::string& p, Resnet* r, std::vector<std::string>* tw, std::vector<std::string>* tb);
+    int pack_xformer(const std::string& p, Xformer* x, int heads, int depth);
+    int run(Ctx& c, const half_t* sample, const float* timesteps, const half_t* ehs, int L,
+            const half_t* add_text, const float* add_time_ids, half_t* out, int B, int H, int W);
+};
+
+struct VAE {
+    explicit VAE(const sd_vae_config& c);
+    int finalize();
+    int decode(const half_t* z, half_t* img, int B, int h, int w, hipStream_t stream);
+    int encode(const half_t* img, half_t* moments, int B, int H, int W, hipStream_t stream);
+
+    sd_vae_config cfg;
+    WeightStore ws;
+    Arena arena;
+    bool finalized = false;
+    long planned_key = -1;
+
+    // decoder
+    half_t* pq_w = nullptr; float* pq_b = nullptr;      // post_quant_conv (pointwise, NCHW)
+    ConvW d_conv_in, d_conv_out;
+    NormW d_norm_out;
+    Resnet d_mid0, d_mid1;
+    VaeAttn d_attn;
+    std::vector<std::vector<Resnet>> d_up;
+    std::vector<ConvW> d_us;
+    // encoder
+    half_t* q_w = nullptr; float* q_b = nullptr;        // quant_conv
+    ConvW e_conv_in, e_conv_out;
+    NormW e_norm_out;
+    Resnet e_mid0, e_mid1;
+    VaeAttn e_attn;
+    std::vector<std::vector<Resnet>> e_down;
+    std::vector<ConvW> e_ds;
+
+  private:
+    int pack_resnet(const std::string& p, Resnet* r);
+    int pack_attn(const std::string& p, VaeAttn* a);
+    int pack_pointwise(const std::string& p, half_t** w, float** b);
+    void run_attn(Ctx& c, const VaeAttn& a, View x, int N, int H, int W, View out);
+    int run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w);
+    int run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W);
+};
+
+}  // namespace sd

@@ -1,0 +1,289 @@
+// Arena, weight store and op wrappers of the denoise engine (host side, HIP runtime only).
+#include "engine.h"
+
+#include <cstring>
+
+namespace sd {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+const std::string& last_error() { return g_last_error; }
+
+// ------------------------------------------------------------------------------------------ Arena
+Arena::~Arena() {
+    if (base_) (void)hipFree(base_);
+}
+
+int Arena::reserve(size_t bytes) {
+    if (bytes <= cap_) return 0;
+    if (base_) { (void)hipFree(base_); base_ = nullptr; cap_ = 0; }
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base_), bytes));
+    cap_ = bytes;
+    return 0;
+}
+
+void* Arena::alloc(size_t bytes) {
+    const size_t aligned = (bytes + 255) & ~size_t(255);
+    const size_t at = off_;
+    off_ += aligned;
+    if (off_ > peak_) peak_ = off_;
+    if (dry_) return reinterpret_cast<void*>(uintptr_t(0x1000) + at);  // never dereferenced
+    if (off_ > cap_) { overflow_ = true; return base_; }
+    return base_ + at;
+}
+
+// ------------------------------------------------------------------------------------ WeightStore
+WeightStore::~WeightStore() {
+    free_raw();
+    for (void* p : owned_) (void)hipFree(p);
+}
+
+void* WeightStore::dmalloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return nullptr;
+    owned_.push_back(p);
+    packed_bytes_ += (int64_t)bytes;
+    return p;
+}
+
+void WeightStore::declare(const std::string& key, std::vector<int64_t> shape) {
+    RawTensor t;
+    t.shape = std::move(shape);
+    t.numel = 1;
+    for (auto s : t.shape) t.numel *= s;
+    tensors.emplace(key, std::move(t));
+    order.push_back(key);
+}
+
+int WeightStore::set(const std::string& key, const void* data, const int64_t* shape, int ndim, int dtype) {
+    auto it = tensors.find(key);
+    if (it == tensors.end()) { set_error("unknown weight key: " + key); return 1; }
+    RawTensor& t = it->second;
+    if ((int)t.shape.size() != ndim) { set_error("rank mismatch for " + key); return 1; }
+    for (int i = 0; i < ndim; ++i)
+        if (t.shape[i] != shape[i]) {
+            set_error("shape mismatch for " + key + " at dim " + std::to_string(i) + ": expected " +
+                      std::to_string(t.shape[i]) + ", got " + std::to_string(shape[i]));
+            return 1;
+        }
+    if (!t.dev) SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&t.dev), (size_t)t.numel * sizeof(half_t)));
+    if (dtype == 0) {
+        SD_HIP_CHECK(hipMemcpy(t.dev, data, (size_t)t.numel * sizeof(half_t), hipMemcpyDefault));
+    } else if (dtype == 1) {
+        float* tmp = nullptr;
+        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)t.numel * sizeof(float)));
+        hipError_t e = hipMemcpy(tmp, data, (size_t)t.numel * sizeof(float), hipMemcpyDefault);
+        int rc = 0;
+        if (e == hipSuccess) rc = launch_f32_to_f16(tmp, t.dev, t.numel, 0);
+        if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(0);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) { set_error(std::string("set_weight copy: ") + hipGetErrorString(e)); return 3; }
+        if (rc) return rc;
+    } else {
+        set_error("unsupported dtype code");
+        return 1;
+    }
+    return 0;
+}
+
+bool WeightStore::complete(std::string* missing) const {
+    for (const auto& k : order) {
+        auto it = tensors.find(k);
+        if (it == tensors.end() || !it->second.dev) {
+            if (missing) *missing = k;
+            return false;
+        }
+    }
+    return true;
+}
+
+const RawTensor* WeightStore::raw(const std::string& key) const {
+    auto it = tensors.find(key);
+    if (it == tensors.end() || !it->second.dev) return nullptr;
+    return &it->second;
+}
+
+void WeightStore::free_raw() {
+    for (auto& kv : tensors)
+        if (kv.second.dev) { (void)hipFree(kv.second.dev); kv.second.dev = nullptr; }
+}
+
+int WeightStore::host_floats(const std::string& key, std::vector<float>* out) const {
+    const RawTensor* t = raw(key);
+    if (!t) { set_error("missing weight: " + key); return 2; }
+    std::vector<half_t> h((size_t)t->numel);
+    SD_HIP_CHECK(hipMemcpy(h.data(), t->dev, (size_t)t->numel * sizeof(half_t), hipMemcpyDeviceToHost));
+    out->resize((size_t)t->numel);
+    for (long i = 0; i < t->numel; ++i) (*out)[(size_t)i] = (float)h[(size_t)i];
+    return 0;
+}
+
+static long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+static int upload_bias(WeightStore* ws, const std::vector<float>& host, int cout, float** dst) {
+    const long padded = round_up(cout, kWeightRowPad);
+    std::vector<float> buf((size_t)padded, 0.f);
+    std::memcpy(buf.data(), host.data(), (size_t)cout * sizeof(float));
+    *dst = static_cast<float*>(ws->dmalloc((size_t)padded * sizeof(float)));
+    if (!*dst) { set_error("hipMalloc failed (bias)"); return 3; }
+    SD_HIP_CHECK(hipMemcpy(*dst, buf.data(), (size_t)padded * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int WeightStore::pack_conv(const std::string& prefix, ConvW* out, bool has_bias) {
+    const RawTensor* w = raw(prefix + ".weight");
+    if (!w) { set_error("missing weight: " + prefix + ".weight"); return 2; }
+    const int O = (int)w->shape[0], I = (int)w->shape[1];
+    const int KH = w->shape.size() == 4 ? (int)w->shape[2] : 1;
+    const int KW = w->shape.size() == 4 ? (int)w->shape[3] : 1;
+    const long K = round_up((long)KH * KW * I, 64);
+    const long rows = round_up(O, kWeightRowPad);
+    out->cin = I; out->cout = O; out->ks = KH; out->K = K;
+    out->w = static_cast<half_t*>(dmalloc((size_t)rows * K * sizeof(half_t)));
+    if (!out->w) { set_error("hipMalloc failed (weights)"); return 3; }
+    SD_HIP_CHECK(hipMemsetAsync(out->w, 0, (size_t)rows * K * sizeof(half_t), 0));
+    int rc = launch_pack_conv(w->dev, out->w, O, I, KH, KW, K, 0);
+    if (rc) return rc;
+    out->bias = nullptr;
+    if (has_bias) {
+        std::vector<float> b;
+        rc = host_floats(prefix + ".bias", &b);
+        if (rc) return rc;
+        rc = upload_bias(this, b, O, &out->bias);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int WeightStore::pack_rows(const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys,
+                           ConvW* out) {
+    long total = 0;
+    int I = -1;
+    for (const auto& k : wkeys) {
+        const RawTensor* w = raw(k);
+        if (!w) { set_error("missing weight: " + k); return 2; }
+        if (I < 0) I = (int)w->shape[1];
+        if ((int)w->shape[1] != I) { set_error("pack_rows: inner dims differ at " + k); return 1; }
+        total += w->shape[0];
+    }
+    if (I % 64 != 0) { set_error("pack_rows: inner dim must be a multiple of 64"); return 1; }
+    const long rows = round_up(total, kWeightRowPad);
+    out->cin = I; out->cout = (int)total; out->ks = 1; out->K = I;
+    out->w = static_cast<half_t*>(dmalloc((size_t)rows * I * sizeof(half_t)));
+    if (!out->w) { set_error("hipMalloc failed (weights)"); return 3; }
+    SD_HIP_CHECK(hipMemsetAsync(out->w, 0, (size_t)rows * I * sizeof(half_t), 0));
+    long r = 0;
+    for (const auto& k : wkeys) {
+        const RawTensor* w = raw(k);
+        SD_HIP_CHECK(hipMemcpyAsync(out->w + r * I, w->dev, (size_t)w->numel * sizeof(half_t),
+                                    hipMemcpyDeviceToDevice, 0));
+        r += w->shape[0];
+    }
+    out->bias = nullptr;
+    if (!bkeys.empty()) {
+        std::vector<float> all;
+        for (const auto& k : bkeys) {
+            std::vector<float> b;
+            int rc = host_floats(k, &b);
+            if (rc) return rc;
+            all.insert(all.end(), b.begin(), b.end());
+        }
+        if ((long)all.size() != total) { set_error("pack_rows: bias length mismatch"); return 1; }
+        int rc = upload_bias(this, all, (int)total, &out->bias);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// GEGLU projection [8C][C]: rows 0..4C-1 = hidden, 4C..8C-1 = gate (diffusers GEGLU: hidden, gate =
+// proj.chunk(2)).  Packed so that every 128-row group holds 64 hidden rows followed by their 64
+// gate rows -- the igemm epilogue then finds both halves of out = hidden * gelu(gate) in one tile.
+int WeightStore::pack_geglu(const std::string& prefix, ConvW* out) {
+    const RawTensor* w = raw(prefix + ".weight");
+    if (!w) { set_error("missing weight: " + prefix + ".weight"); return 2; }
+    const long O = w->shape[0], I = w->shape[1];
+    const long half_rows = O / 2;
+    if (half_rows % 64 != 0 || I % 64 != 0) { set_error("pack_geglu: dims must be multiples of 64"); return 1; }
+    const long rows = round_up(O, kWeightRowPad);
+    out->cin = (int)I; out->cout = (int)O; out->ks = 1; out->K = I;
+    out->w = static_cast<half_t*>(dmalloc((size_t)rows * I * sizeof(half_t)));
+    if (!out->w) { set_error("hipMalloc failed (weights)"); return 3; }
+    SD_HIP_CHECK(hipMemsetAsync(out->w, 0, (size_t)rows * I * sizeof(half_t), 0));
+    std::vector<float> b, bp((size_t)O);
+    int rc = host_floats(prefix + ".bias", &b);
+    if (rc) return rc;
+    for (long blk = 0; blk < half_rows / 64; ++blk) {
+        SD_HIP_CHECK(hipMemcpyAsync(out->w + (blk * 128) * I, w->dev + (blk * 64) * I,
+                                    (size_t)64 * I * sizeof(half_t), hipMemcpyDeviceToDevice, 0));
+        SD_HIP_CHECK(hipMemcpyAsync(out->w + (blk * 128 + 64) * I, w->dev + (half_rows + blk * 64) * I,
+                                    (size_t)64 * I * sizeof(half_t), hipMemcpyDeviceToDevice, 0));
+        for (int e = 0; e < 64; ++e) {
+            bp[(size_t)(blk * 128 + e)] = b[(size_t)(blk * 64 + e)];
+            bp[(size_t)(blk * 128 + 64 + e)] = b[(size_t)(half_rows + blk * 64 + e)];
+        }
+    }
+    return upload_bias(this, bp, (int)O, &out->bias);
+}
+
+int WeightStore::pack_norm(const std::string& prefix, NormW* out) {
+    std::vector<float> g, b;
+    int rc = host_floats(prefix + ".weight", &g);
+    if (rc) return rc;
+    rc = host_floats(prefix + ".bias", &b);
+    if (rc) return rc;
+    out->C = (int)g.size();
+    out->gamma = static_cast<float*>(dmalloc(g.size() * sizeof(float)));
+    out->beta = static_cast<float*>(dmalloc(b.size() * sizeof(float)));
+    if (!out->gamma || !out->beta) { set_error("hipMalloc failed (norm)"); return 3; }
+    SD_HIP_CHECK(hipMemcpy(out->gamma, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+    SD_HIP_CHECK(hipMemcpy(out->beta, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------- ops
+void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride, int up,
+             const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad) {
+    if (c.dry || c.err) return;
+    IGemmParams p;
+    p.x = x.p; p.ldx = x.ld;
+    p.w = w.w; p.bias = w.bias;
+    p.rowadd = rowadd; p.rowadd_ld = rowadd_ld;
+    p.res = res ? res->p : nullptr; p.ldres = res ? res->ld : 0;
+    p.y = y.p; p.ldy = y.ld;
+    p.N = N; p.H = H; p.W = W; p.Cin = (w.ks == 1) ? (int)w.K : w.cin;
+    p.KS = w.ks; p.stride = stride; p.up = up;
+    p.pad = pad >= 0 ? pad : (w.ks == 3 ? 1 : 0);
+    const int IH = H << up, IW = W << up;
+    if (stride == 1) {
+        p.OH = IH; p.OW = IW;
+    } else if (p.pad == 0) {
+        // VAE encoder Downsample2D: F.pad (0,1,0,1) then stride-2 conv with padding 0 -> the
+        // right / bottom zero column is the gather's ordinary bounds check.
+        p.OH = (IH + 1 - w.ks) / stride + 1; p.OW = (IW + 1 - w.ks) / stride + 1;
+    } else {
+        p.OH = (IH + 2 * p.pad - w.ks) / stride + 1; p.OW = (IW + 2 * p.pad - w.ks) / stride + 1;
+    }
+    p.Cout = w.cout;
+    p.M = N * p.OH * p.OW;
+    p.K = (int)w.K;
+    p.geglu = geglu;
+    c.err = launch_igemm(p, c.stream);
+}
+
+void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu) {
+    float* scratch = c.arena->alloc_f(gn_scratch_floats(N, HW, n.C, G));
+    if (c.dry || c.err) return;
+    c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream);
+}
+
+void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps) {
+    if (c.dry || c.err) return;
+    c.err = launch_layernorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, rows, n.C, eps, c.stream);
+}
+
+void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d) {
+    if (c.dry || c.err) return;
+    c.err = launch_attention(q.p, k.p, v.p, out.p, B, Tq, Tk, heads, d, q.ld, k.ld, v.ld, out.ld, c.stream);
+}
+
+}  // namespace sd

@@ -1,0 +1,498 @@
+// UNet2DConditionModel graph on the gfx950 kernels.
+//
+// What it computes: diffusers 0.27.2 UNet2DConditionModel.forward as the reference calls it at
+// /root/reference/pipelines/sd_unified_pipeline.py:475-482 (structure: SURVEY.md §3.3; weight names:
+// /root/reference/scripts/convert_from_A1111.py:283-441).  How it runs is native to MI355X:
+// NHWC fp16 activations, skip connections written straight into the concatenation buffers of the
+// up path (no torch.cat copies), fused qkv / GEGLU / residual / time-embedding epilogues, one
+// stacked GEMV for all 22 time_emb_proj layers, and a stack-discipline workspace arena.
+#include "model.h"
+
+namespace sd {
+
+void declare_resnet(WeightStore& ws, const std::string& p, int cin, int cout, int temb) {
+    ws.declare(p + ".norm1.weight", {cin});
+    ws.declare(p + ".norm1.bias", {cin});
+    ws.declare(p + ".conv1.weight", {cout, cin, 3, 3});
+    ws.declare(p + ".conv1.bias", {cout});
+    if (temb) {
+        ws.declare(p + ".time_emb_proj.weight", {cout, temb});
+        ws.declare(p + ".time_emb_proj.bias", {cout});
+    }
+    ws.declare(p + ".norm2.weight", {cout});
+    ws.declare(p + ".norm2.bias", {cout});
+    ws.declare(p + ".conv2.weight", {cout, cout, 3, 3});
+    ws.declare(p + ".conv2.bias", {cout});
+    if (cin != cout) {
+        ws.declare(p + ".conv_shortcut.weight", {cout, cin, 1, 1});
+        ws.declare(p + ".conv_shortcut.bias", {cout});
+    }
+}
+
+namespace {
+
+void declare_xformer(WeightStore& ws, const std::string& p, int c, int depth, int ctx, bool linear) {
+    ws.declare(p + ".norm.weight", {c});
+    ws.declare(p + ".norm.bias", {c});
+    if (linear) ws.declare(p + ".proj_in.weight", {c, c}); else ws.declare(p + ".proj_in.weight", {c, c, 1, 1});
+    ws.declare(p + ".proj_in.bias", {c});
+    for (int d = 0; d < depth; ++d) {
+        const std::string b = p + ".transformer_blocks." + std::to_string(d);
+        ws.declare(b + ".norm1.weight", {c});
+        ws.declare(b + ".norm1.bias", {c});
+        ws.declare(b + ".attn1.to_q.weight", {c, c});
+        ws.declare(b + ".attn1.to_k.weight", {c, c});
+        ws.declare(b + ".attn1.to_v.weight", {c, c});
+        ws.declare(b + ".attn1.to_out.0.weight", {c, c});
+        ws.declare(b + ".attn1.to_out.0.bias", {c});
+        ws.declare(b + ".norm2.weight", {c});
+        ws.declare(b + ".norm2.bias", {c});
+        ws.declare(b + ".attn2.to_q.weight", {c, c});
+        ws.declare(b + ".attn2.to_k.weight", {c, ctx});
+        ws.declare(b + ".attn2.to_v.weight", {c, ctx});
+        ws.declare(b + ".attn2.to_out.0.weight", {c, c});
+        ws.declare(b + ".attn2.to_out.0.bias", {c});
+        ws.declare(b + ".norm3.weight", {c});
+        ws.declare(b + ".norm3.bias", {c});
+        ws.declare(b + ".ff.net.0.proj.weight", {8 * c, c});
+        ws.declare(b + ".ff.net.0.proj.bias", {8 * c});
+        ws.declare(b + ".ff.net.2.weight", {c, 4 * c});
+        ws.declare(b + ".ff.net.2.bias", {c});
+    }
+    if (linear) ws.declare(p + ".proj_out.weight", {c, c}); else ws.declare(p + ".proj_out.weight", {c, c, 1, 1});
+    ws.declare(p + ".proj_out.bias", {c});
+}
+
+}  // namespace
+
+UNet::UNet(const sd_unet_config& c) : cfg(c) {
+    const int nb = cfg.num_blocks;
+    const int* boc = cfg.block_out_channels;
+    const int temb = boc[0] * 4;
+    const int ctx = cfg.cross_attention_dim;
+    const bool lin = cfg.use_linear_projection != 0;
+    ws.declare("conv_in.weight", {boc[0], cfg.in_channels, 3, 3});
+    ws.declare("conv_in.bias", {boc[0]});
+    ws.declare("time_embedding.linear_1.weight", {temb, boc[0]});
+    ws.declare("time_embedding.linear_1.bias", {temb});
+    ws.declare("time_embedding.linear_2.weight", {temb, temb});
+    ws.declare("time_embedding.linear_2.bias", {temb});
+    if (cfg.addition_time_embed_dim > 0) {
+        ws.declare("add_embedding.linear_1.weight", {temb, cfg.projection_class_embeddings_input_dim});
+        ws.declare("add_embedding.linear_1.bias", {temb});
+        ws.declare("add_embedding.linear_2.weight", {temb, temb});
+        ws.declare("add_embedding.linear_2.bias", {temb});
+    }
+    int out_ch = boc[0];
+    for (int i = 0; i < nb; ++i) {
+        const int in_ch = out_ch;
+        out_ch = boc[i];
+        for (int j = 0; j < cfg.layers_per_block; ++j) {
+            const std::string p = "down_blocks." + std::to_string(i);
+            declare_resnet(ws, p + ".resnets." + std::to_string(j), j == 0 ? in_ch : out_ch, out_ch, temb);
+            if (cfg.down_block_has_attn[i])
+                declare_xformer(ws, p + ".attentions." + std::to_string(j), out_ch, cfg.transformer_layers[i], ctx, lin);
+        }
+        if (i != nb - 1) {
+            ws.declare("down_blocks." + std::to_string(i) + ".downsamplers.0.conv.weight", {out_ch, out_ch, 3, 3});
+            ws.declare("down_blocks." + std::to_string(i) + ".downsamplers.0.conv.bias", {out_ch});
+        }
+    }
+    const int mid = boc[nb - 1];
+    declare_resnet(ws, "mid_block.resnets.0", mid, mid, temb);
+    declare_xformer(ws, "mid_block.attentions.0", mid, cfg.transformer_layers[nb - 1], ctx, lin);
+    declare_resnet(ws, "mid_block.resnets.1", mid, mid, temb);
+    out_ch = boc[nb - 1];
+    for (int i = 0; i < nb; ++i) {
+        const int prev = out_ch;
+        out_ch = boc[nb - 1 - i];
+        const int in_ch = boc[nb - 1 - (i + 1 < nb ? i + 1 : nb - 1)];
+        const std::string p = "up_blocks." + std::to_string(i);
+        for (int j = 0; j < cfg.layers_per_block + 1; ++j) {
+            const int skip = (j == cfg.layers_per_block) ? in_ch : out_ch;
+            const int rin = (j == 0) ? prev : out_ch;
+            declare_resnet(ws, p + ".resnets." + std::to_string(j), rin + skip, out_ch, temb);
+            if (cfg.up_block_has_attn[i])
+                declare_xformer(ws, p + ".attentions." + std::to_string(j), out_ch,
+                                cfg.transformer_layers[nb - 1 - i], ctx, lin);
+        }
+        if (i != nb - 1) {
+            ws.declare(p + ".upsamplers.0.conv.weight", {out_ch, out_ch, 3, 3});
+            ws.declare(p + ".upsamplers.0.conv.bias", {out_ch});
+        }
+    }
+    ws.declare("conv_norm_out.weight", {boc[0]});
+    ws.declare("conv_norm_out.bias", {boc[0]});
+    ws.declare("conv_out.weight", {cfg.out_channels, boc[0], 3, 3});
+    ws.declare("conv_out.bias", {cfg.out_channels});
+}
+
+int UNet::pack_resnet(const std::string& p, Resnet* r, std::vector<std::string>* tw, std::vector<std::string>* tb) {
+    int rc;
+    if ((rc = ws.pack_norm(p + ".norm1", &r->n1))) return rc;
+    if ((rc = ws.pack_conv(p + ".conv1", &r->c1))) return rc;
+    if ((rc = ws.pack_norm(p + ".norm2", &r->n2))) return rc;
+    if ((rc = ws.pack_conv(p + ".conv2", &r->c2))) return rc;
+    r->cin = r->c1.cin; r->cout = r->c1.cout;
+    r->has_sc = ws.raw(p + ".conv_shortcut.weight") != nullptr;
+    if (r->has_sc && (rc = ws.pack_conv(p + ".conv_shortcut", &r->sc))) return rc;
+    if (tw) {
+        r->temb_off = temb_total;
+        temb_total += r->cout;
+        tw->push_back(p + ".time_emb_proj.weight");
+        tb->push_back(p + ".time_emb_proj.bias");
+    }
+    return 0;
+}
+
+int UNet::pack_xformer(const std::string& p, Xformer* x, int heads, int depth) {
+    int rc;
+    if ((rc = ws.pack_norm(p + ".norm", &x->gn))) return rc;
+    if ((rc = ws.pack_conv(p + ".proj_in", &x->pin))) return rc;
+    if ((rc = ws.pack_conv(p + ".proj_out", &x->pout))) return rc;
+    x->C = x->pin.cout;
+    x->heads = heads;
+    x->blocks.resize((size_t)depth);
+    for (int d = 0; d < depth; ++d) {
+        TBlock& b = x->blocks[(size_t)d];
+        const std::string q = p + ".transformer_blocks." + std::to_string(d);
+        if ((rc = ws.pack_norm(q + ".norm1", &b.ln1))) return rc;
+        if ((rc = ws.pack_norm(q + ".norm2", &b.ln2))) return rc;
+        if ((rc = ws.pack_norm(q + ".norm3", &b.ln3))) return rc;
+        if ((rc = ws.pack_rows({q + ".attn1.to_q.weight", q + ".attn1.to_k.weight", q + ".attn1.to_v.weight"}, {}, &b.qkv))) return rc;
+        if ((rc = ws.pack_conv(q + ".attn1.to_out.0", &b.out1))) return rc;
+        if ((rc = ws.pack_conv(q + ".attn2.to_q", &b.q2, false))) return rc;
+        if ((rc = ws.pack_rows({q + ".attn2.to_k.weight", q + ".attn2.to_v.weight"}, {}, &b.kv2))) return rc;
+        if ((rc = ws.pack_conv(q + ".attn2.to_out.0", &b.out2))) return rc;
+        if ((rc = ws.pack_geglu(q + ".ff.net.0.proj", &b.ff1))) return rc;
+        if ((rc = ws.pack_conv(q + ".ff.net.2", &b.ff2))) return rc;
+    }
+    return 0;
+}
+
+int UNet::finalize() {
+    if (finalized) return 0;
+    std::string missing;
+    if (!ws.complete(&missing)) { set_error("finalize: weight not set: " + missing); return 2; }
+    const int nb = cfg.num_blocks;
+    int rc;
+    std::vector<std::string> tw, tb;
+    temb_total = 0;
+    if ((rc = ws.pack_conv("conv_in", &conv_in))) return rc;
+    if ((rc = ws.pack_conv("time_embedding.linear_1", &te1))) return rc;
+    if ((rc = ws.pack_conv("time_embedding.linear_2", &te2))) return rc;
+    if (cfg.addition_time_embed_dim > 0) {
+        if ((rc = ws.pack_conv("add_embedding.linear_1", &ae1))) return rc;
+        if ((rc = ws.pack_conv("add_embedding.linear_2", &ae2))) return rc;
+    }
+    down_res.assign((size_t)nb, {}); down_att.assign((size_t)nb, {}); down_ds.assign((size_t)nb, ConvW());
+    up_res.assign((size_t)nb, {}); up_att.assign((size_t)nb, {}); up_us.assign((size_t)nb, ConvW());
+    for (int i = 0; i < nb; ++i) {
+        const std::string p = "down_blocks." + std::to_string(i);
+        down_res[i].resize((size_t)cfg.layers_per_block);
+        if (cfg.down_block_has_attn[i]) down_att[i].resize((size_t)cfg.layers_per_block);
+        for (int j = 0; j < cfg.layers_per_block; ++j) {
+            if ((rc = pack_resnet(p + ".resnets." + std::to_string(j), &down_res[i][j], &tw, &tb))) return rc;
+            if (cfg.down_block_has_attn[i] &&
+                (rc = pack_xformer(p + ".attentions." + std::to_string(j), &down_att[i][j], cfg.num_heads[i],
+                                   cfg.transformer_layers[i]))) return rc;
+        }
+        if (i != nb - 1 && (rc = ws.pack_conv(p + ".downsamplers.0.conv", &down_ds[i]))) return rc;
+    }
+    if ((rc = pack_resnet("mid_block.resnets.0", &mid_r0, &tw, &tb))) return rc;
+    if ((rc = pack_xformer("mid_block.attentions.0", &mid_att, cfg.num_heads[nb - 1], cfg.transformer_layers[nb - 1]))) return rc;
+    if ((rc = pack_resnet("mid_block.resnets.1", &mid_r1, &tw, &tb))) return rc;
+    for (int i = 0; i < nb; ++i) {
+        const std::string p = "up_blocks." + std::to_string(i);
+        up_res[i].resize((size_t)cfg.layers_per_block + 1);
+        if (cfg.up_block_has_attn[i]) up_att[i].resize((size_t)cfg.layers_per_block + 1);
+        for (int j = 0; j < cfg.layers_per_block + 1; ++j) {
+            if ((rc = pack_resnet(p + ".resnets." + std::to_string(j), &up_res[i][j], &tw, &tb))) return rc;
+            if (cfg.up_block_has_attn[i] &&
+                (rc = pack_xformer(p + ".attentions." + std::to_string(j), &up_att[i][j], cfg.num_heads[nb - 1 - i],
+                                   cfg.transformer_layers[nb - 1 - i]))) return rc;
+        }
+        if (i != nb - 1 && (rc = ws.pack_conv(p + ".upsamplers.0.conv", &up_us[i]))) return rc;
+    }
+    if ((rc = ws.pack_norm("conv_norm_out", &norm_out))) return rc;
+    if ((rc = ws.pack_conv("conv_out", &conv_out))) return rc;
+    if ((rc = ws.pack_rows(tw, tb, &temb_stack))) return rc;
+    SD_HIP_CHECK(hipDeviceSynchronize());
+    ws.free_raw();
+    finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ blocks
+void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
+                const float* tproj, int tproj_ld) {
+    Arena& a = *c.arena;
+    const size_t mk = a.mark();
+    const long M = (long)N * H * W;
+    View h1(a.alloc_h(M * r.cin), r.cin, r.cin);
+    op_groupnorm(c, r.n1, x, h1, N, (long)H * W, G, eps, 1);
+    View h2(a.alloc_h(M * r.cout), r.cout, r.cout);
+    op_conv(c, r.c1, h1, N, H, W, h2, 1, 0, tproj ? tproj + r.temb_off : nullptr, tproj_ld);
+    View h3(a.alloc_h(M * r.cout), r.cout, r.cout);
+    op_groupnorm(c, r.n2, h2, h3, N, (long)H * W, G, eps, 1);
+    View res = x;
+    if (r.has_sc) {
+        res = View(a.alloc_h(M * r.cout), r.cout, r.cout);
+        op_conv(c, r.sc, x, N, H, W, res);
+    }
+    op_conv(c, r.c2, h3, N, H, W, out, 1, 0, nullptr, 0, &res);
+    a.release(mk);
+}
+
+void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G,
+                 const half_t* ehs, int L, int ctx_dim) {
+    Arena& a = *c.arena;
+    const size_t mk = a.mark();
+    const int C = t.C;
+    const int T = H * W;
+    const long M = (long)N * T;
+    const int d = C / t.heads;
+    View hn(a.alloc_h(M * C), C, C);
+    op_groupnorm(c, t.gn, x, hn, N, T, G, 1e-6f, 0);
+    View cur(a.alloc_h(M * C), C, C), nxt(a.alloc_h(M * C), C, C);
+    op_conv(c, t.pin, hn, N, H, W, cur);
+    View ctx(const_cast<half_t*>(ehs), ctx_dim, ctx_dim);
+    for (const TBlock& b : t.blocks) {
+        const size_t mb = a.mark();
+        View n(a.alloc_h(M * C), C, C);
+        op_layernorm(c, b.ln1, cur, n, M, 1e-5f);
+        View qkv(a.alloc_h(M * 3 * C), 3 * C, 3 * C);
+        op_conv(c, b.qkv, n, N, H, W, qkv);
+        View att(a.alloc_h(M * C), C, C);
+        op_attention(c, qkv.slice(0, C), qkv.slice(C, C), qkv.slice(2 * C, C), att, N, T, T, t.heads, d);
+        View t2(a.alloc_h(M * C), C, C);
+        op_conv(c, b.out1, att, N, H, W, t2, 1, 0, nullptr, 0, &cur);
+        op_layernorm(c, b.ln2, t2, n, M, 1e-5f);
+        View q(a.alloc_h(M * C), C, C);
+        op_conv(c, b.q2, n, N, H, W, q);
+        View kv(a.alloc_h((long)N * L * 2 * C), 2 * C, 2 * C);
+        op_conv(c, b.kv2, ctx, N, L, 1, kv);
+        op_attention(c, q, kv.slice(0, C), kv.slice(C, C), att, N, T, L, t.heads, d);
+        View t3(a.alloc_h(M * C), C, C);
+        op_conv(c, b.out2, att, N, H, W, t3, 1, 0, nullptr, 0, &t2);
+        op_layernorm(c, b.ln3, t3, n, M, 1e-5f);
+        View g(a.alloc_h(M * 4 * C), 4 * C, 4 * C);
+        op_conv(c, b.ff1, n, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1);
+        op_conv(c, b.ff2, g, N, H, W, nxt, 1, 0, nullptr, 0, &t3);
+        a.release(mb);
+        View tmp = cur; cur = nxt; nxt = tmp;
+    }
+    op_conv(c, t.pout, cur, N, H, W, out, 1, 0, nullptr, 0, &x);
+    a.release(mk);
+}
+
+// ----------------------------------------------------------------------------------------- forward
+int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t* ehs, int L,
+              const half_t* add_text, const float* add_time_ids, half_t* out, int B, int H, int W) {
+    Arena& a = *c.arena;
+    const int nb = cfg.num_blocks;
+    const int* boc = cfg.block_out_channels;
+    const int G = cfg.norm_num_groups;
+    const float eps = cfg.norm_eps;
+    const int temb = boc[0] * 4;
+    hipStream_t s = c.stream;
+    const bool go = !c.dry;
+
+    // ---- time embedding (fp32, batch-sized GEMVs) ----
+    float* sinus = a.alloc_f((long)B * boc[0]);
+    float* e1 = a.alloc_f((long)B * temb);
+    float* emb = a.alloc_f((long)B * temb);
+    float* tproj = a.alloc_f((long)B * temb_total);
+    if (go && !c.err) c.err = launch_timestep_sinusoid(timesteps, 1, sinus, B, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift, boc[0], s);
+    if (go && !c.err) c.err = launch_small_linear(sinus, boc[0], te1.w, te1.bias, e1, temb, B, boc[0], temb, 0, 1, s);
+    if (go && !c.err) c.err = launch_small_linear(e1, temb, te2.w, te2.bias, emb, temb, B, temb, temb, 0, 0, s);
+    if (cfg.addition_time_embed_dim > 0) {
+        const int ad = cfg.addition_time_embed_dim;
+        const int pin = cfg.projection_class_embeddings_input_dim;
+        const int tdim = pin - 6 * ad;          // pooled text embedding width
+        if (!add_text || !add_time_ids) { set_error("unet: add_text / add_time_ids required for text_time conditioning"); return 1; }
+        float* addin = a.alloc_f((long)B * pin);
+        float* a1 = a.alloc_f((long)B * temb);
+        float* aug = a.alloc_f((long)B * temb);
+        float* txt = a.alloc_f((long)B * tdim);
+        if (go && !c.err) c.err = launch_f16_to_f32(add_text, txt, (long)B * tdim, s);
+        if (go && !c.err) {
+            hipError_t e = hipMemcpy2DAsync(addin, (size_t)pin * 4, txt, (size_t)tdim * 4, (size_t)tdim * 4, (size_t)B,
+                                            hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) { set_error(hipGetErrorString(e)); c.err = 3; }
+        }
+        // time_ids.flatten() -> [B*6] scalars -> sinusoid(ad) each -> [B, 6*ad] placed after the text
+        if (go && !c.err) {
+            for (int j = 0; j < 6 && !c.err; ++j)
+                c.err = launch_timestep_sinusoid(add_time_ids + j, 6, addin + tdim + j * ad, B, ad,
+                                                         cfg.flip_sin_to_cos, cfg.freq_shift, pin, s);
+        }
+        if (go && !c.err) c.err = launch_small_linear(addin, pin, ae1.w, ae1.bias, a1, temb, B, pin, temb, 0, 1, s);
+        if (go && !c.err) c.err = launch_small_linear(a1, temb, ae2.w, ae2.bias, aug, temb, B, temb, temb, 0, 0, s);
+        if (go && !c.err) c.err = launch_add_f32(emb, aug, (long)B * temb, s);
+    }
+    if (go && !c.err) c.err = launch_small_linear(emb, temb, temb_stack.w, temb_stack.bias, tproj, temb_total, B, temb, temb_total, 1, 0, s);
+
+    // ---- skip / concat buffer plan ----
+    // Skip tensors are produced in down-path order and consumed by the up path in reverse; each
+    // up resnet k reads cat_k = [hidden (C1) | skip (C2)].  Allocate every cat_k up front so the
+    // down-path producers write their outputs directly into the skip half.
+    struct Cat { half_t* p; int c1, c2, h, w; };
+    std::vector<Cat> cats;
+    {
+        int out_ch = boc[nb - 1];
+        int h = H >> (nb - 1), w = W >> (nb - 1);
+        for (int i = 0; i < nb; ++i) {
+            const int prev = out_ch;
+            out_ch = boc[nb - 1 - i];
+            const int in_ch = boc[nb - 1 - (i + 1 < nb ? i + 1 : nb - 1)];
+            for (int j = 0; j < cfg.layers_per_block + 1; ++j) {
+                Cat ct;
+                ct.c2 = (j == cfg.layers_per_block) ? in_ch : out_ch;
+                ct.c1 = (j == 0) ? prev : out_ch;
+                ct.h = h; ct.w = w;
+                ct.p = a.alloc_h((long)B * h * w * (ct.c1 + ct.c2));
+                cats.push_back(ct);
+            }
+            if (i != nb - 1) { h *= 2; w *= 2; }
+        }
+    }
+    const int nskip = (int)cats.size();
+    int skip_i = 0;   // index of the next skip to produce; consumer is cats[nskip-1-skip_i]
+    auto skip_view = [&](int si) {
+        const Cat& ct = cats[(size_t)(nskip - 1 - si)];
+        return View(ct.p + ct.c1, ct.c1 + ct.c2, ct.c2);
+    };
+
+    // ---- conv_in (Cin = 4: im2col into a 64-wide K, then the GEMM kernel) ----
+    int h = H, w = W;
+    {
+        const size_t mk = a.mark();
+        const long M = (long)B * H * W;
+        half_t* col = a.alloc_h(M * conv_in.K);
+        if (go && !c.err) c.err = launch_im2col_nchw3x3(sample, col, B, cfg.in_channels, H, W, (int)conv_in.K, s);
+        ConvW pw = conv_in; pw.ks = 1;
+        op_conv(c, pw, View(col, conv_in.K, (int)conv_in.K), B, H, W, skip_view(skip_i));
+        a.release(mk);
+    }
+    View x = skip_view(skip_i++);
+
+    // ---- down path ----
+    for (int i = 0; i < nb; ++i) {
+        for (int j = 0; j < cfg.layers_per_block; ++j) {
+            const Resnet& r = down_res[i][j];
+            if (cfg.down_block_has_attn[i]) {
+                const size_t mk = a.mark();
+                View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
+                run_resnet(c, r, x, B, h, w, tmp, G, eps, tproj, temb_total);
+                View dst = skip_view(skip_i);
+                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, ehs, L, cfg.cross_attention_dim);
+                a.release(mk);
+                x = dst;
+            } else {
+                View dst = skip_view(skip_i);
+                run_resnet(c, r, x, B, h, w, dst, G, eps, tproj, temb_total);
+                x = dst;
+            }
+            ++skip_i;
+        }
+        if (i != nb - 1) {
+            View dst = skip_view(skip_i++);
+            op_conv(c, down_ds[i], x, B, h, w, dst, 2, 0);
+            h /= 2; w /= 2;
+            x = dst;
+        }
+    }
+
+    // ---- mid block ----
+    {
+        const int C = boc[nb - 1];
+        const long M = (long)B * h * w;
+        View m0(a.alloc_h(M * C), C, C), m1(a.alloc_h(M * C), C, C);
+        run_resnet(c, mid_r0, x, B, h, w, m0, G, eps, tproj, temb_total);
+        run_xformer(c, mid_att, m0, B, h, w, m1, G, ehs, L, cfg.cross_attention_dim);
+        const Cat& ct = cats[0];
+        View dst(ct.p, ct.c1 + ct.c2, ct.c1);
+        run_resnet(c, mid_r1, m1, B, h, w, dst, G, eps, tproj, temb_total);
+    }
+
+    // ---- up path ----
+    View final_x;
+    int k = 0;
+    for (int i = 0; i < nb; ++i) {
+        for (int j = 0; j < cfg.layers_per_block + 1; ++j, ++k) {
+            const Cat& ct = cats[(size_t)k];
+            const Resnet& r = up_res[i][j];
+            View xin(ct.p, ct.c1 + ct.c2, ct.c1 + ct.c2);
+            const bool last_in_block = (j == cfg.layers_per_block);
+            const bool last = last_in_block && i == nb - 1;
+            // destination of this layer's output: next cat's hidden half, an upsample input, or the tail
+            View dst;
+            const size_t mk = a.mark();
+            if (!last_in_block) {
+                const Cat& nx = cats[(size_t)k + 1];
+                dst = View(nx.p, nx.c1 + nx.c2, nx.c1);
+            } else {
+                dst = View(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
+            }
+            if (cfg.up_block_has_attn[i]) {
+                View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
+                run_resnet(c, r, xin, B, h, w, tmp, G, eps, tproj, temb_total);
+                run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, ehs, L, cfg.cross_attention_dim);
+            } else {
+                run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total);
+            }
+            if (last) {
+                final_x = dst;   // the temporary stays alive for the tail
+            } else {
+                if (last_in_block) {
+                    const Cat& nx = cats[(size_t)k + 1];
+                    View up_dst(nx.p, nx.c1 + nx.c2, nx.c1);
+                    op_conv(c, up_us[i], dst, B, h, w, up_dst, 1, 1);
+                    h *= 2; w *= 2;
+                }
+                a.release(mk);
+            }
+        }
+    }
+
+    // ---- tail: GN + SiLU + conv_out, back to NCHW ----
+    {
+        const int C = boc[0];
+        const long M = (long)B * h * w;
+        View hn(a.alloc_h(M * C), C, C);
+        op_groupnorm(c, norm_out, final_x, hn, B, (long)h * w, G, eps, 1);
+        View y(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
+        op_conv(c, conv_out, hn, B, h, w, y);
+        if (go && !c.err) c.err = launch_nhwc_to_nchw(y.p, y.ld, out, B, (long)h * w, cfg.out_channels, s);
+    }
+    return c.err;
+}
+
+int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ehs, int L, const half_t* add_text,
+                  const float* add_time_ids, half_t* out, int B, int H, int W, hipStream_t stream) {
+    if (!finalized) { set_error("unet: forward before finalize"); return 2; }
+    const int div = 1 << (cfg.num_blocks - 1);
+    if (B <= 0 || H % div != 0 || W % div != 0) { set_error("unet: H and W must be divisible by 2^(blocks-1)"); return 1; }
+    const long key = ((long)B << 40) ^ ((long)H << 20) ^ (long)W ^ ((long)L << 52);
+    if (key != planned_key) {
+        Ctx dry{&arena, stream, true};
+        arena.begin(true);
+        int rc = run(dry, sample, timesteps, ehs, L, add_text, add_time_ids, out, B, H, W);
+        if (rc) return rc;
+        // growing the slab frees the old one: make sure nothing enqueued earlier still uses it
+        if (arena.peak() > arena.capacity()) {
+            SD_HIP_CHECK(hipDeviceSynchronize());
+            rc = arena.reserve(arena.peak());
+            if (rc) return rc;
+        }
+        planned_key = key;
+    }
+    Ctx ctx{&arena, stream, false};
+    arena.begin(false);
+    int rc = run(ctx, sample, timesteps, ehs, L, add_text, add_time_ids, out, B, H, W);
+    if (!rc && arena.overflow()) { set_error("unet: workspace overflow (planner bug)"); return 2; }
+    return rc;
+}
+
+}  // namespace sd

@@ -1,0 +1,340 @@
+"""Host-side mirror of the reference's pipeline surface, driving the gfx950 engine.
+
+`StableDiffusionUnifiedPipeline` keeps the constructor and the 26 `__call__` keyword arguments of
+`/root/reference/pipelines/sd_unified_pipeline.py:116-166` and the same control flow for the
+txt2img (`:216-231`) and img2img (`:236-264`) branches, the denoise loop (`:465-507`) and the VAE
+decode (`:511-523`); `SDModelWrapper` keeps the attribute surface of
+`/root/reference/models/stable_diffusion.py:40-103,187-227` (`.base .vae .text_encoder .tokenizer
+.scheduler .vae_scale_factor .device .set_scheduler`).  What sits in `.base` / `.vae` is the HIP
+engine (stablediffusion_amd.models) instead of diffusers modules.
+
+Differences from the reference, on purpose:
+  * `prompt_embeds= / negative_prompt_embeds= / pooled_*` are accepted (superset): the build box has
+    no tokenizer vocabulary or CLIP weights, and the benchmark feeds synthetic embeddings.  The
+    reference raises when `prompt is None` (`:565`).
+  * reference defects listed in SURVEY.md §8b (relative import, tqdm.notebook, unbound `generator`,
+    …) are not reproduced.  Quirk kept: the `output_type` kwarg is ignored, the constructor's wins.
+  * inpainting (`:268-380`, `:492-506`) is not implemented yet (SURVEY.md §8f is "next").
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Union
+
+import torch
+
+from . import schedulers as _sched
+
+
+class SDModelWrapper:
+    """Holder of the five sub-models + scheduler (reference: models/stable_diffusion.py:40-103)."""
+
+    def __init__(self, base=None, vae=None, text_encoder=None, tokenizer=None, scheduler=None,
+                 text_encoder_2=None, tokenizer_2=None, model_type: str = "sd15", device: str = "cuda",
+                 model_name: Optional[str] = None):
+        self.base = base
+        self.vae = vae
+        self.text_encoder = text_encoder
+        self.tokenizer = tokenizer
+        if model_type == "sdxl":
+            self.text_encoder_2 = text_encoder_2
+            self.tokenizer_2 = tokenizer_2
+        self.scheduler = scheduler if scheduler is not None else _sched.EulerDiscreteScheduler()
+        self.scheduler_name = "euler"
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        self.device = torch.device(device)
+        self.type = model_type
+        self.name = model_name
+        self.path = None
+
+    def to(self, device):
+        self.vae.to(device)
+        self.base.to(device)
+        if self.text_encoder is not None:
+            self.text_encoder.to(device)
+        if getattr(self, "text_encoder_2", None) is not None:
+            self.text_encoder_2.to(device)
+        self.device = torch.device(device)
+
+    def set_scheduler(self, scheduler_name):
+        """Registry of models/stable_diffusion.py:199-227 (names the engine's host code implements)."""
+        if getattr(self, "scheduler_name", None) == scheduler_name:
+            return
+        if scheduler_name not in _sched.REGISTRY:
+            raise ValueError(f"Unknown scheduler name: {scheduler_name}")
+        self.scheduler = _sched.REGISTRY[scheduler_name](self.scheduler.config)
+        self.scheduler_name = scheduler_name
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, **kwargs):
+    """sd_unified_pipeline.py:61-95 (the custom timesteps / sigmas branches are never reached there)."""
+    scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+    return scheduler.timesteps, num_inference_steps
+
+
+def denoising_value_valid(dnv):
+    return isinstance(dnv, float) and 0 < dnv < 1
+
+
+class StableDiffusionUnifiedPipeline:
+    def __init__(self, do_cfg: bool = True, device: Optional[str] = None, output_type: Optional[str] = None):
+        self.do_classifier_free_guidance = bool(do_cfg)
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.output_type = output_type if output_type is not None else "pt"
+        self.model: Optional[SDModelWrapper] = None
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(
+        self,
+        model: SDModelWrapper,
+        prompt: Union[str, List[str], None] = None,
+        prompt_2=None,
+        negative_prompt=None,
+        negative_prompt_2=None,
+        height: Optional[int] = None,
+        width: Optional[int] = None,
+        num_images_per_prompt: Optional[int] = 1,
+        num_inference_steps: int = 50,
+        denoising_end: Optional[float] = None,
+        guidance_scale: float = 5.0,
+        latents: Optional[torch.Tensor] = None,
+        output_type: Optional[str] = "pt",
+        cross_attention_kwargs: Optional[Dict[str, Any]] = None,
+        guidance_rescale: float = 0.0,
+        clip_skip: Optional[int] = None,
+        seed: Optional[int] = None,
+        image=None,
+        strength: float = 1.0,
+        denoising_start: Optional[float] = None,
+        mask_image=None,
+        masked_image_latents=None,
+        padding_mask_crop: Optional[int] = None,
+        # superset (see module docstring)
+        prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        pooled_prompt_embeds: Optional[torch.Tensor] = None,
+        negative_pooled_prompt_embeds: Optional[torch.Tensor] = None,
+    ):
+        if model.device != self.device:
+            model.to(self.device)
+        self.model = model
+        if mask_image is not None:
+            raise NotImplementedError("inpainting is not part of the engine yet (SURVEY.md §8f)")
+
+        height = height or model.base.config.sample_size * model.vae_scale_factor
+        width = width or model.base.config.sample_size * model.vae_scale_factor
+
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        elif prompt_embeds is not None:
+            batch_size = prompt_embeds.shape[0]
+        else:
+            raise ValueError("either `prompt` or `prompt_embeds` is required")
+
+        if prompt_embeds is None:
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = \
+                self.encode_prompt(prompt, prompt_2, negative_prompt, negative_prompt_2,
+                                   num_images_per_prompt, None, clip_skip)
+        else:
+            prompt_embeds = prompt_embeds.to(self.device)
+            if self.do_classifier_free_guidance:
+                if negative_prompt_embeds is None:
+                    raise ValueError("negative_prompt_embeds is required with prompt_embeds when CFG is on")
+                negative_prompt_embeds = negative_prompt_embeds.to(self.device)
+
+        timesteps, num_inference_steps = retrieve_timesteps(model.scheduler, num_inference_steps, self.device)
+
+        if image is None:
+            shape = (batch_size * num_images_per_prompt, model.base.config.in_channels,
+                     height // model.vae_scale_factor, width // model.vae_scale_factor)
+            latents = self.prepare_latents_txt2img(shape, prompt_embeds.dtype, seed, latents)
+        else:
+            timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, denoising_start)
+            latent_timestep = timesteps[:1].repeat(batch_size * num_images_per_prompt)
+            add_noise = denoising_start is None
+            latents = self.prepare_latents_img2img(image, latent_timestep, batch_size, num_images_per_prompt,
+                                                   prompt_embeds.dtype, seed, add_noise)
+
+        if (denoising_end is not None and denoising_start is not None and denoising_value_valid(denoising_end)
+                and denoising_value_valid(denoising_start) and denoising_start >= denoising_end):
+            raise ValueError(f"`denoising_start`: {denoising_start} cannot be larger than or equal to "
+                             f"`denoising_end`:  {denoising_end} when using type float.")
+        elif denoising_end is not None and denoising_value_valid(denoising_end):
+            cutoff = int(round(model.scheduler.config.num_train_timesteps
+                               - denoising_end * model.scheduler.config.num_train_timesteps))
+            num_inference_steps = len([ts for ts in timesteps if ts >= cutoff])
+            timesteps = timesteps[:num_inference_steps]
+
+        # SDXL added conditions (:407-435)
+        if getattr(model.base.config, "addition_embed_type", None) == "text_time":
+            add_text_embeds = pooled_prompt_embeds
+            add_time_ids = self._get_add_time_ids((height, width), (0, 0), (height, width), prompt_embeds.dtype)
+            add_time_ids = add_time_ids.repeat(batch_size * num_images_per_prompt, 1)
+            if self.do_classifier_free_guidance:
+                add_text_embeds = torch.cat([negative_pooled_prompt_embeds, add_text_embeds], dim=0)
+                add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0)
+            added_cond_kwargs = {"text_embeds": add_text_embeds.to(self.device),
+                                 "time_ids": add_time_ids.to(self.device)}
+        else:
+            added_cond_kwargs = None
+
+        if self.do_classifier_free_guidance:
+            prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        prompt_embeds = prompt_embeds.to(self.device)
+
+        # ---- denoising loop (:465-507) ----
+        for i, t in enumerate(timesteps):
+            latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
+            latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
+            noise_pred = model.base(latent_model_input, t, prompt_embeds,
+                                    cross_attention_kwargs=cross_attention_kwargs,
+                                    added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+            if self.do_classifier_free_guidance:
+                noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+                noise_pred = guidance_scale * (noise_pred_text - noise_pred_uncond) + noise_pred_uncond
+            latents = model.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+
+        # ---- decode (:511-529) ----
+        if self.output_type == "pt":
+            cfg = model.vae.config
+            mean = getattr(cfg, "latents_mean", None)
+            std = getattr(cfg, "latents_std", None)
+            if mean is not None and std is not None:
+                m = torch.tensor(mean).view(1, -1, 1, 1).to(latents.device, latents.dtype)
+                s = torch.tensor(std).view(1, -1, 1, 1).to(latents.device, latents.dtype)
+                latents = latents * s / cfg.scaling_factor + m
+            else:
+                latents = latents / cfg.scaling_factor
+            images = model.vae.decode(latents, return_dict=False)[0]
+        elif self.output_type == "latents":
+            images = latents
+        else:
+            raise ValueError(f"Unknown output_type = '{self.output_type}'")
+        return images
+
+    # ------------------------------------------------------------------------------------------
+    def encode_prompt(self, prompt, prompt_2=None, negative_prompt=None, negative_prompt_2=None,
+                      num_images_per_prompt=1, lora_scale=None, clip_skip=None):
+        """sd_unified_pipeline.py:532-719: CLIP stays host PyTorch-ROCm (north_star)."""
+        m = self.model
+        if m.tokenizer is None or m.text_encoder is None:
+            raise ValueError("model has no tokenizer / text_encoder: pass prompt_embeds instead")
+        sdxl = hasattr(m, "text_encoder_2") and hasattr(m, "tokenizer_2")
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt)
+        toks, encs, prompts = [m.tokenizer], [m.text_encoder], [prompt]
+        if sdxl:
+            prompt_2 = prompt_2 or prompt
+            prompt_2 = [prompt_2] if isinstance(prompt_2, str) else prompt_2
+            toks, encs, prompts = [m.tokenizer, m.tokenizer_2], [m.text_encoder, m.text_encoder_2], [prompt, prompt_2]
+
+        def run(texts_list):
+            embeds, pooled = [], None
+            for texts, tok, enc in zip(texts_list, toks, encs):
+                ids = tok(texts, padding="max_length", max_length=tok.model_max_length, truncation=True,
+                          return_tensors="pt").input_ids.to(self.device)
+                out = enc(ids, output_hidden_states=True)
+                pooled = out[0]
+                if clip_skip is None:
+                    e = out.hidden_states[-2] if sdxl else out[0]
+                else:
+                    e = (out.hidden_states[-(clip_skip + 2)] if sdxl
+                         else enc.text_model.final_layer_norm(out[-1][-(clip_skip + 1)]))
+                embeds.append(e)
+            return torch.concat(embeds, dim=-1), pooled
+
+        prompt_embeds, pooled = run(prompts)
+        neg_embeds = neg_pooled = None
+        if self.do_classifier_free_guidance:
+            negative_prompt = negative_prompt or ""
+            negative_prompt_2 = negative_prompt_2 or negative_prompt
+            negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            negative_prompt_2 = (batch_size * [negative_prompt_2] if isinstance(negative_prompt_2, str)
+                                 else negative_prompt_2)
+            if batch_size != len(negative_prompt):
+                raise ValueError("`negative_prompt` batch size does not match `prompt`")
+            neg_embeds, neg_pooled = run([negative_prompt, negative_prompt_2])
+        dt = m.base.dtype
+        bs, seq, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.to(dtype=dt, device=self.device).repeat(1, num_images_per_prompt, 1)
+        prompt_embeds = prompt_embeds.view(bs * num_images_per_prompt, seq, -1)
+        if neg_embeds is not None:
+            neg_embeds = neg_embeds.to(dtype=dt, device=self.device).repeat(1, num_images_per_prompt, 1)
+            neg_embeds = neg_embeds.view(batch_size * num_images_per_prompt, seq, -1)
+        if sdxl:
+            pooled = pooled.repeat(1, num_images_per_prompt).view(bs * num_images_per_prompt, -1)
+            if neg_pooled is not None:
+                neg_pooled = neg_pooled.repeat(1, num_images_per_prompt).view(bs * num_images_per_prompt, -1)
+        return prompt_embeds, neg_embeds, pooled, neg_pooled
+
+    def get_timesteps(self, num_inference_steps, strength, denoising_start=None):
+        """sd_unified_pipeline.py:722-761."""
+        sch = self.model.scheduler
+        if denoising_start is None:
+            init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+            t_start = max(num_inference_steps - init_timestep, 0)
+        else:
+            t_start = 0
+        timesteps = sch.timesteps[t_start * sch.order:]
+        if denoising_start is not None:
+            cutoff = int(round(sch.config.num_train_timesteps - denoising_start * sch.config.num_train_timesteps))
+            n = int((timesteps < cutoff).sum().item())
+            if sch.order == 2 and n % 2 == 0:
+                n += 1
+            return timesteps[-n:], n
+        return timesteps, num_inference_steps - t_start
+
+    def prepare_latents_txt2img(self, shape, dtype, seed=None, latents=None):
+        """sd_unified_pipeline.py:764-787 (generator lives on self.device, like the reference)."""
+        generator = None
+        if seed is not None:
+            generator = torch.Generator(device=self.device).manual_seed(int(seed))
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device=self.device, dtype=dtype)
+        else:
+            latents = latents.to(self.device)
+        return latents * self.model.scheduler.init_noise_sigma
+
+    def prepare_latents_img2img(self, image, timestep, batch_size, num_images_per_prompt, dtype, seed=None,
+                                add_noise=True):
+        """sd_unified_pipeline.py:790-845."""
+        if not isinstance(image, torch.Tensor):
+            raise ValueError(f"`image` has to be a torch.Tensor in [-1, 1] (got {type(image)})")
+        image = image.to(device=self.device, dtype=dtype)
+        batch_size = batch_size * num_images_per_prompt
+        generator = None
+        if seed is not None:
+            generator = torch.Generator(device=self.device).manual_seed(int(seed))
+        if image.shape[1] == 4:
+            init_latents = image
+        else:
+            init_latents = self._encode_vae_image(image, generator)
+        if batch_size > init_latents.shape[0] and batch_size % init_latents.shape[0] == 0:
+            init_latents = torch.cat([init_latents] * (batch_size // init_latents.shape[0]), dim=0)
+        elif batch_size > init_latents.shape[0]:
+            raise ValueError(f"Cannot duplicate `image` of batch size {init_latents.shape[0]} to {batch_size} text prompts.")
+        if add_noise:
+            noise = torch.randn(init_latents.shape, generator=generator, device=self.device, dtype=dtype)
+            init_latents = self.model.scheduler.add_noise(init_latents, noise, timestep)
+        return init_latents
+
+    def _encode_vae_image(self, image, generator):
+        """sd_unified_pipeline.py:1017-1041."""
+        vae = self.model.vae
+        dist = vae.encode(image).latent_dist
+        z = dist.sample(generator)
+        return (z * vae.config.scaling_factor).to(image.dtype)
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype):
+        """sd_unified_pipeline.py:979-1014."""
+        ids = list(original_size + crops_coords_top_left + target_size)
+        cfg = self.model.base.config
+        passed = cfg.addition_time_embed_dim * len(ids) + (cfg.projection_class_embeddings_input_dim
+                                                          - 6 * cfg.addition_time_embed_dim)
+        expected = self.model.base.add_embedding.linear_1.in_features
+        if passed != expected:
+            raise ValueError(f"Model expects an added time embedding vector of length {expected}, "
+                             f"but a vector of {passed} was created.")
+        return torch.tensor([ids], dtype=dtype)

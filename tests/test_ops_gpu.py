@@ -1,0 +1,181 @@
+"""Parity of each HIP operator against a plain PyTorch fp32 CPU reference of the same op, through
+the C-ABI (sd_op_* in include/sd_engine.h).  Inputs are rounded to fp16 first so both sides see
+identical operands; tolerance = fp16 output rounding + fp32-accumulation order (stated per test)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def h(t):
+    return t.half().cuda().contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, up, bias/rowadd/res
+    (2, 16, 16, 64, 64, 3, 1, 0, True),
+    (2, 16, 16, 128, 320, 3, 1, 0, True),      # Cout = 2.5 tiles of 128
+    (1, 32, 32, 320, 320, 3, 1, 0, True),      # SD1.5 level-0 channel count
+    (2, 16, 16, 64, 128, 3, 2, 0, True),       # Downsample2D
+    (2, 8, 8, 128, 128, 3, 1, 1, True),        # Upsample2D: nearest 2x folded into the gather
+    (2, 12, 20, 192, 64, 1, 1, 0, True),       # 1x1 conv / linear, ragged M
+    (1, 7, 9, 64, 72, 3, 1, 0, False),         # ragged M and Cout % 64 != 0
+    (3, 8, 8, 640, 1280, 1, 1, 0, False),
+    (1, 8, 8, 1280, 1280, 3, 1, 0, True),      # small M, long K
+    (1, 16, 16, 64, 4, 3, 1, 0, False),        # conv_out: Cout = 4 (scalar epilogue)
+    (1, 16, 16, 64, 3, 3, 1, 0, False),        # VAE conv_out: Cout = 3
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(engine_lib, case):
+    N, H, W, Cin, Cout, k, stride, up, extras = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half()
+    bias = torch.randn(Cout, generator=g) * 0.5 if extras else None
+    rowadd = torch.randn(N, Cout, generator=g) * 0.5 if extras else None
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1 if k == 3 else 0)
+    if rowadd is not None:
+        ref = ref + rowadd[:, :, None, None]
+    res = torch.randn(ref.shape, generator=g).half() if extras else None
+    if res is not None:
+        # engine rounds the conv result to fp16 before the residual add, like an fp16 torch graph
+        ref = ref.half().float() + res.float()
+    OH, OW = ref.shape[2], ref.shape[3]
+    y = torch.empty(N, OH, OW, Cout, dtype=torch.float16, device="cuda")
+    x_nhwc = h(x.permute(0, 2, 3, 1))
+    res_nhwc = h(res.permute(0, 2, 3, 1)) if res is not None else None
+    # keep every device tensor referenced until the call has completed
+    wd = h(w)
+    bd = bias.cuda() if bias is not None else None
+    rd = rowadd.cuda().contiguous() if rowadd is not None else None
+    rc = engine_lib.sd_op_conv2d(P(x_nhwc), P(wd), P(bd), P(rd), P(res_nhwc), P(y),
+                                 N, H, W, Cin, Cout, k, stride, up, 0, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 2e-3            # fp16 output rounding: ~5e-4 relative
+
+
+def test_conv_geglu(engine_lib):
+    """Linear(C, 8C) + GEGLU epilogue: hidden * gelu(gate) with the 64-row interleaved packing."""
+    g = torch.Generator().manual_seed(7)
+    N, T, Cc = 2, 96, 64
+    x = torch.randn(N * T, Cc, generator=g).half()
+    w = (torch.randn(8 * Cc, Cc, generator=g) / Cc ** 0.5).half()
+    b = torch.randn(8 * Cc, generator=g) * 0.2
+    proj = (x.float() @ w.float().t() + b).half().float()
+    hid, gate = proj.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate)
+    y = torch.empty(N * T, 4 * Cc, dtype=torch.float16, device="cuda")
+    xd, wd, bd = h(x), h(w), b.cuda()
+    rc = engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, None, P(y), N, T, 1, Cc, 8 * Cc, 1, 1, 0, 1,
+                                 stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 2e-3
+
+
+@pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 256, 64, 1, 1e-5), (2, 1024, 320, 1, 1e-5),
+                                             (1, 64, 1920, 1, 1e-5), (3, 100, 128, 0, 1e-6),
+                                             (1, 4096, 2560, 1, 1e-5), (2, 33, 960, 0, 1e-6)])
+def test_groupnorm(engine_lib, N, HW, C, silu, eps):
+    g = torch.Generator().manual_seed(C + HW)
+    x = (torch.randn(N, HW, C, generator=g) * 1.5 + 0.7).half()
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1)
+    y = torch.empty(N, HW, C, dtype=torch.float16, device="cuda")
+    xd, gd, bd = h(x), gamma.cuda(), beta.cuda()
+    rc = engine_lib.sd_op_groupnorm(P(xd), P(gd), P(bd), P(y), N, HW, C, 32, eps, silu, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("rows,C", [(300, 320), (1000, 640), (77, 1280), (5, 64)])
+def test_layernorm(engine_lib, rows, C):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).half()
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    y = torch.empty(rows, C, dtype=torch.float16, device="cuda")
+    xd, gd, bd = h(x), gamma.cuda(), beta.cuda()
+    rc = engine_lib.sd_op_layernorm(P(xd), P(gd), P(bd), P(y), rows, C, 1e-5, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 1.5e-3
+
+
+ATTN_CASES = [
+    # B, Tq, Tk, heads, d
+    (2, 256, 256, 8, 40),      # SD1.5 level 0 head dim (padded 40 -> 64 / 48)
+    (1, 1024, 1024, 8, 80),
+    (2, 256, 256, 8, 160),
+    (2, 64, 64, 8, 160),       # 8x8 latents: one partial query block
+    (2, 256, 77, 8, 40),       # cross attention, ragged keys
+    (1, 100, 77, 5, 64),       # SDXL head dim, ragged queries
+    (2, 128, 77, 4, 32),       # test-config head dim
+    (1, 320, 320, 1, 512),     # VAE mid-block attention (single head over 512 channels)
+    (1, 192, 192, 1, 128),     # tiny-VAE mid-block
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention(engine_lib, case):
+    B, Tq, Tk, H, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    q = torch.randn(B, Tq, H * d, generator=g).half()
+    k = torch.randn(B, Tk, H * d, generator=g).half()
+    v = torch.randn(B, Tk, H * d, generator=g).half()
+    ref = F.scaled_dot_product_attention(q.float().view(B, Tq, H, d).transpose(1, 2),
+                                         k.float().view(B, Tk, H, d).transpose(1, 2),
+                                         v.float().view(B, Tk, H, d).transpose(1, 2))
+    ref = ref.transpose(1, 2).reshape(B, Tq, H * d)
+    out = torch.empty(B, Tq, H * d, dtype=torch.float16, device="cuda")
+    qd, kd, vd = h(q), h(k), h(v)
+    rc = engine_lib.sd_op_attention(P(qd), P(kd), P(vd), P(out), B, Tq, Tk, H, d, H * d, H * d, H * d, H * d,
+                                    stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    # P is rounded to fp16 before the PV product (like fp16 SDPA): ~1e-3 relative
+    assert rel_l2(out, ref) < 3e-3
+
+
+def test_attention_online_softmax_rescale(engine_lib):
+    """Force the running-max rescale branch: one key far above the rest in a LATER key tile."""
+    B, T, H, d = 1, 256, 2, 64
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B, T, H * d, generator=g).half()
+    k = (torch.randn(B, T, H * d, generator=g) * 0.3).half()
+    v = torch.randn(B, T, H * d, generator=g).half()
+    k[:, 200] = q[:, 17] * 2.0        # spikes the score of query 17 at key 200 (4th tile)
+    ref = F.scaled_dot_product_attention(q.float().view(B, T, H, d).transpose(1, 2),
+                                         k.float().view(B, T, H, d).transpose(1, 2),
+                                         v.float().view(B, T, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, T, H * d)
+    out = torch.empty(B, T, H * d, dtype=torch.float16, device="cuda")
+    qd, kd, vd = h(q), h(k), h(v)
+    rc = engine_lib.sd_op_attention(P(qd), P(kd), P(vd), P(out), B, T, T, H, d, H * d, H * d, H * d, H * d, stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 3e-3
+    assert (out[0, 17].float().cpu() - ref[0, 17]).abs().max() < 2e-2
