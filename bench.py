@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on the MI355X engine.
+
+metric : denoise-loop latents/s (512px, 50-step DDIM, batch 4 per GPU) = images / wall time of
+         [denoise loop sd_unified_pipeline.py:465-507 + VAE decode :511-523], text encoding excluded.
+step   : one full pass of the hot path over one batch: 50 UNet forwards at CFG batch 8 + scheduler
+         steps + one VAE decode of 4 latents, driven through StableDiffusionUnifiedPipeline.__call__.
+inputs : synthetic: latents N(0,1) [4,4,64,64] seed 0, text embeddings N(0,1)
+         [4,77,768] x2 seed 1, weights N(0,1/fan_in) seed 2, all resident in HBM before timing.
+N > 1  : one process per GPU (torchrun), weak scaling: every rank denoises its own 4 latents; rank 0
+         broadcasts the text embeddings and images are all-gathered (RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+measured live with HIP events on the launch stream) and `cpu_baseline` (the fp32 CPU oracle timed
+on a bounded sample of the same workload; N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from stablediffusion_amd import _lib, config, distributed as sdd, weights  # noqa: E402
+from stablediffusion_amd.models import HipAutoencoderKL, HipUNet2DConditionModel  # noqa: E402
+from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline  # noqa: E402
+from stablediffusion_amd.schedulers import DDIMScheduler  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md:43
+HBM_PEAK_GBS = 8000.0       # spec; 6.29 TB/s achievable (MI355X_MICROARCH.md:36)
+# algorithmic TFLOP per unit (2*MAC of conv / linear / QK^T / PV only)
+UNET_TFLOP_PER_SAMPLE = {32: 0.1803, 64: 0.8032, 96: 2.148, 128: 4.674}
+VAE_TFLOP_PER_IMAGE = {32: 0.622, 64: 2.515, 96: 5.754, 128: 10.470}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_models(device, preset="sd15", seed=2):
+    ucfg, vcfg = (f() for f in config.PRESETS[preset])
+    t0 = time.time()
+    usd = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=seed, dtype=torch.float16)
+    vsd = weights.synth_state_dict(weights.vae_manifest(vcfg), seed=seed + 1, dtype=torch.float16)
+    unet = HipUNet2DConditionModel(ucfg, device).load_state_dict(usd)
+    vae = HipAutoencoderKL(vcfg, device).load_state_dict(vsd)
+    log(f"[bench] weights synthesised + packed in {time.time() - t0:.1f}s; "
+        f"unet {unet.memory()[0] / 1e9:.2f} GB, vae {vae.memory()[0] / 1e9:.2f} GB packed")
+    return ucfg, vcfg, usd, vsd, unet, vae
+
+
+def live_roofline(lib, unet, vae, B, lat_hw, ehs, device):
+    """One profiled UNet forward (CFG batch 2B) + one decode: per-kernel HIP-event times."""
+    x = torch.randn(2 * B, 4, lat_hw, lat_hw, device=device, dtype=torch.float16)
+    z = torch.randn(B, 4, lat_hw, lat_hw, device=device, dtype=torch.float16)
+    t = torch.tensor(501.0)
+    unet(x, t, ehs)           # warm
+    torch.cuda.synchronize()
+    lib.sd_prof_enable(1)
+    unet(x, t, ehs)
+    ents = (_lib.SdProfEntry * 64)()
+    n = C.c_int()
+    _lib.check(lib.sd_prof_collect(ents, 64, C.byref(n)), "sd_prof_collect")
+    unet_rows = [(e.kernel.decode(), e.flops, e.bytes, e.ms, e.launches) for e in ents[: n.value]]
+    vae.decode(z)
+    _lib.check(lib.sd_prof_collect(ents, 64, C.byref(n)), "sd_prof_collect")
+    vae_rows = [(e.kernel.decode(), e.flops, e.bytes, e.ms, e.launches) for e in ents[: n.value]]
+    lib.sd_prof_enable(0)
+    return unet_rows, vae_rows
+
+
+def usable_cores() -> int:
+    """Host cores this process may really use: cgroup quota, then affinity, capped at the GPU
+    box's per-GPU CPU share (16) so torch does not oversubscribe a 256-core host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("SD_BENCH_CPU_THREADS", min(n, 16)))
+
+
+def cpu_baseline(ucfg, vcfg, usd, vsd, steps, lat_hw, ehs_len):
+    """fp32 CPU oracle ("port") on a bounded sample of the same workload: one UNet forward at CFG
+    batch 2 (= one latent) and one VAE decode of one latent, both at a quarter of the latent area,
+    scaled to the full resolution by the algorithmic-FLOP ratio of SURVEY.md §8(d)."""
+    from oracle import unet_ref, vae_ref
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    hw = lat_hw // 2
+    u_scale = UNET_TFLOP_PER_SAMPLE.get(lat_hw, 4 * UNET_TFLOP_PER_SAMPLE.get(hw, 1)) / UNET_TFLOP_PER_SAMPLE.get(hw, 1)
+    v_scale = VAE_TFLOP_PER_IMAGE.get(lat_hw, 4 * VAE_TFLOP_PER_IMAGE.get(hw, 1)) / VAE_TFLOP_PER_IMAGE.get(hw, 1)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        uw = {k: v.float() for k, v in usd.items()}
+        x = torch.randn(2, 4, hw, hw, generator=g)
+        e = torch.randn(2, ehs_len, ucfg.cross_attention_dim, generator=g)
+        t0 = time.time()
+        unet_ref.unet_forward(ucfg, uw, x, torch.tensor(501.0), e)
+        t_unet = time.time() - t0
+        del uw
+        vw = {k: v.float() for k, v in vsd.items()}
+        z = torch.randn(1, 4, hw, hw, generator=g)
+        t0 = time.time()
+        vae_ref.vae_decode(vcfg, vw, z)
+        t_vae = time.time() - t0
+    per_latent = steps * t_unet * u_scale + t_vae * v_scale
+    return {
+        "value": 1.0 / per_latent, "unit": "latents/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle (fp32 torch CPU restatement of the reference's diffusers path), {cores} threads: "
+                   f"1 UNet forward at CFG batch 2 on {hw}x{hw} latents = {t_unet:.2f}s, x{u_scale:.2f} (FLOP ratio to "
+                   f"{lat_hw}x{lat_hw}) x {steps} steps; 1 VAE decode of a {hw}x{hw} latent = {t_vae:.2f}s, x{v_scale:.2f}"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed passes of the whole hot path")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=4, help="latents per GPU")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--guidance", type=float, default=5.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = sdd.init()
+    if world != args.gpus and world > 1:
+        log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
+    n_gpus = max(world, 1)
+    _lib.require_gpu()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    lib = _lib.load()
+
+    ucfg, vcfg, usd, vsd, unet, vae = build_models(device)
+    model = SDModelWrapper(base=unet, vae=vae, scheduler=DDIMScheduler(), device=str(device))
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device=str(device))
+
+    B = args.batch
+    lat_hw = args.res // 8
+    total = B * n_gpus
+    # full-batch synthetic inputs from single seeded CPU generators, then resident in HBM
+    lat_full = torch.randn(total, 4, lat_hw, lat_hw, generator=torch.Generator().manual_seed(0)).half().to(device)
+    ge = torch.Generator().manual_seed(1)
+    pe_full = torch.randn(total, 77, ucfg.cross_attention_dim, generator=ge).half().to(device)
+    ne_full = torch.randn(total, 77, ucfg.cross_attention_dim, generator=ge).half().to(device)
+    if rank != 0:   # non-root ranks receive the embeddings through the broadcast
+        pe_full.zero_(); ne_full.zero_()
+
+    def one_pass():
+        return sdd.sharded_txt2img(pipe, model, lat_full, pe_full, ne_full, rank, n_gpus,
+                                   num_inference_steps=args.denoise_steps, guidance_scale=args.guidance,
+                                   height=args.res, width=args.res)
+
+    for _ in range(args.warmup):
+        imgs = one_pass()
+    sdd.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        imgs = one_pass()
+    torch.cuda.synchronize(); sdd.barrier()
+    dt = sdd.max_over_ranks(time.perf_counter() - t0, device)
+    assert imgs.shape == (total, 3, args.res, args.res), imgs.shape
+    finite = bool(torch.isfinite(imgs.float()).all().item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = total * args.steps / dt
+
+    # UNet-only / VAE-only times (per GPU), same shapes as the loop
+    x8 = torch.randn(2 * B, 4, lat_hw, lat_hw, device=device, dtype=torch.float16)
+    e8 = torch.cat([ne_full[:B], pe_full[:B]])
+    tt = torch.tensor(501.0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    unet(x8, tt, e8); vae.decode(x8[:B])
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(10):
+        unet(x8, tt, e8)
+    ev[1].record(); ev[2].record()
+    for _ in range(3):
+        vae.decode(x8[:B])
+    ev[3].record(); torch.cuda.synchronize()
+    unet_ms = ev[0].elapsed_time(ev[1]) / 10
+    vae_ms = ev[2].elapsed_time(ev[3]) / 3
+
+    result = None
+    if rank == 0:
+        u_tf = UNET_TFLOP_PER_SAMPLE.get(lat_hw)
+        v_tf = VAE_TFLOP_PER_IMAGE.get(lat_hw)
+        result = {
+            "metric": "denoise-loop latents/s (512px, 50-step DDIM, batch 4)",
+            "value": round(value, 4), "unit": "latents/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SD1.5 {args.res}x{args.res}, {args.denoise_steps}-step DDIM, "
+                                   f"batch {B}/GPU, CFG on (UNet batch {2 * B}), UNet + VAE decode HIP kernels",
+                       "global_batch": total, "parallelism": f"dp{n_gpus}", "guidance_scale": args.guidance},
+            "unet_forward_ms": round(unet_ms, 3), "vae_decode_ms": round(vae_ms, 3),
+            "outputs_finite": finite,
+        }
+        if u_tf and v_tf:
+            tflop = args.denoise_steps * 2 * B * u_tf + B * v_tf     # per GPU per pass
+            result["whole_path_mfma_frac"] = round(tflop / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4)
+            result["unet_forward_mfma_frac"] = round(2 * B * u_tf / (unet_ms / 1e3) / MFMA_PEAK_TFLOPS, 4)
+        if not args.no_roofline:
+            urows, vrows = live_roofline(lib, unet, vae, B, lat_hw, e8, device)
+            urows.sort(key=lambda r: -r[3])
+            name, flops, nbytes, ms, launches = urows[0]
+            if flops > 0:
+                ach = flops / (ms / 1e3) / 1e12
+                result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2),
+                                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                      "launches_per_unet_forward": launches,
+                                      "avg_launch_us": round(ms / launches * 1e3, 2),
+                                      "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3)}
+            else:
+                ach = nbytes / (ms / 1e3) / 1e9
+                result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                      "traffic": None, "launches_per_unet_forward": launches,
+                                      "avg_launch_us": round(ms / launches * 1e3, 2)}
+            result["kernels_unet_forward"] = [
+                {"kernel": k, "ms": round(m, 3), "launches": l,
+                 "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,
+                 "gbs": round(b / (m / 1e3) / 1e9, 1) if m > 0 else None}
+                for k, f, b, m, l in urows]
+            vrows.sort(key=lambda r: -r[3])
+            result["kernels_vae_decode"] = [
+                {"kernel": k, "ms": round(m, 3), "launches": l,
+                 "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,
+                 "gbs": round(b / (m / 1e3) / 1e9, 1) if m > 0 else None}
+                for k, f, b, m, l in vrows]
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            del unet, vae, model
+            torch.cuda.empty_cache()
+            result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, vsd, args.denoise_steps, lat_hw, 77)
+    sdd.barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

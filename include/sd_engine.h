@@ -136,11 +136,26 @@ int sd_cfg_duplicate(const void* latents, void* out2b, int64_t n_per_batch, int 
 int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float guidance_scale,
                      float c_x, float c_eps, void* stream);
 
+/* -- per-kernel timing for bench.py's live roofline ----------------------------------------- */
+/* While enabled, every conv / norm / attention launch of the models is bracketed by HIP events on
+ * the launch stream.  sd_prof_collect synchronises and returns one aggregate per kernel name:
+ * algorithmic FLOPs and bytes (2*MAC; inputs + weights + outputs once), summed event time. */
+typedef struct sd_prof_entry {
+    char kernel[48];
+    double flops;
+    double bytes;
+    double ms;
+    int64_t launches;
+} sd_prof_entry;
+int sd_prof_enable(int on);
+int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries);
+
 /* -- single operators, exported for the parity tests (tests/test_ops_gpu.py) ----------------- */
 /* Implicit-GEMM convolution / linear on NHWC f16:
  *   y[n,oh,ow,co] = bias[co] + rowadd[n,co] + res[n,oh,ow,co]
  *                 + sum_{kh,kw,ci} x[n, (oh*stride+kh-pad)>>up, (ow*stride+kw-pad)>>up, ci] * w[co,kh,kw,ci]
- * w is PyTorch [Cout,Cin,KH,KW] (f16, device); packed internally per call (test path only). */
+ * w is PyTorch [Cout,Cin,KH,KW] (f16, device), bias [Cout] / rowadd [N,Cout] f32 device (nullable);
+ * packed internally per call (test path only; synchronises). */
 int sd_op_conv2d(const void* x_nhwc, const void* w_oihw, const void* bias, const void* rowadd,
                  const void* res_nhwc, void* y_nhwc, int N, int H, int W, int Cin, int Cout,
                  int ksize, int stride, int upsample2x, int geglu, void* stream);

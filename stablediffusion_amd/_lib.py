@@ -50,6 +50,11 @@ class SdVAEConfig(C.Structure):
     ]
 
 
+class SdProfEntry(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("flops", C.c_double), ("bytes", C.c_double),
+                ("ms", C.c_double), ("launches", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/sd_engine.h declares
 _P = C.c_void_p
 _I = C.c_int
@@ -78,6 +83,8 @@ SIGNATURES = {
     "sd_vae_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "sd_cfg_duplicate": (_I, [_P, _P, _I64, _I, _F, _P]),
     "sd_cfg_ddim_step": (_I, [_P, _P, _I64, _F, _F, _F, _P]),
+    "sd_prof_enable": (_I, [_I]),
+    "sd_prof_collect": (_I, [C.POINTER(SdProfEntry), _I, C.POINTER(_I)]),
     "sd_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sd_op_groupnorm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "sd_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

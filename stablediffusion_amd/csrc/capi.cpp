@@ -1,5 +1,6 @@
 // extern "C" surface of libsd_engine.so -- see include/sd_engine.h for the contract and for the
 // reference interfaces (file:line) each entry point replaces.
+#include <cstdio>
 #include <new>
 
 #include "model.h"
@@ -137,6 +138,24 @@ int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float 
     if (!noise_pred_2b || !latents) { set_error("null argument"); return SD_ERR_INVALID; }
     return launch_cfg_ddim(static_cast<const half_t*>(noise_pred_2b), static_cast<half_t*>(latents), (long)n,
                            guidance_scale, c_x, c_eps, static_cast<hipStream_t>(stream));
+}
+
+// --------------------------------------------------------------------------------------- profiling
+int sd_prof_enable(int on) { prof_enable(on != 0); return SD_OK; }
+int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries) {
+    if (!out || !n_entries) { set_error("null argument"); return SD_ERR_INVALID; }
+    std::map<std::string, ProfAgg> agg;
+    int rc = prof_collect(&agg);
+    if (rc) return rc;
+    int n = 0;
+    for (const auto& kv : agg) {
+        if (n >= max_entries) break;
+        sd_prof_entry& e = out[n++];
+        snprintf(e.kernel, sizeof(e.kernel), "%s", kv.first.c_str());
+        e.flops = kv.second.flops; e.bytes = kv.second.bytes; e.ms = kv.second.ms; e.launches = kv.second.launches;
+    }
+    *n_entries = n;
+    return SD_OK;
 }
 
 // ------------------------------------------------------------------------- single-operator entries

@@ -96,6 +96,14 @@ struct Ctx {
     int err = 0;
 };
 
+// ---- optional per-launch timing (bench.py's live roofline): HIP events on the launch stream ----
+struct ProfAgg { double flops = 0, bytes = 0, ms = 0; long launches = 0; };
+void prof_enable(bool on);
+bool prof_enabled();
+void prof_open(hipStream_t s, const char* kernel, double flops, double bytes);
+void prof_close(hipStream_t s);
+int prof_collect(std::map<std::string, ProfAgg>* out);   // synchronises, aggregates by kernel name
+
 // ---- op wrappers: skip the launch in dry mode, latch the first error ----
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride = 1, int up = 0,
              const float* rowadd = nullptr, int rowadd_ld = 0, const View* res = nullptr, int geglu = 0,

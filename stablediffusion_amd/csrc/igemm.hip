@@ -249,6 +249,25 @@ int launch_cfg(const IGemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+// 0: 128x128, 1: 128x64, 2: 64x64
+static int pick_tile(const IGemmParams& p) {
+    // 128x128 by default; narrower tiles when that removes column padding waste or when the
+    // 128x128 grid would leave most of the 256 CUs idle.
+    const long t128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
+    const bool waste128 = (p.Cout % 128) != 0 && (p.Cout % 128) <= 64;
+    if (!p.geglu && (waste128 || t128 < 192)) {
+        const long t64 = (long)cdiv(p.M, 64) * cdiv(p.Cout, 64);
+        if (t128 < 96 && t64 >= t128 * 2) return 2;
+        return 1;
+    }
+    return 0;
+}
+
+const char* igemm_variant(const IGemmParams& p) {
+    static const char* names[3] = {"igemm_kernel<128,128>", "igemm_kernel<128,64>", "igemm_kernel<64,64>"};
+    return names[pick_tile(p)];
+}
+
 int launch_igemm(const IGemmParams& p, hipStream_t s) {
     if (p.K % BK != 0 || p.Cin % BK != 0) {
         set_error("igemm: K and Cin must be multiples of 64 (pad small-channel inputs via im2col)");
@@ -259,16 +278,11 @@ int launch_igemm(const IGemmParams& p, hipStream_t s) {
         return 1;
     }
     if (p.M <= 0 || p.Cout <= 0) return 0;
-    // Tile choice: 128x128 by default; 128x64 when that removes column padding waste or when the
-    // 128x128 grid would leave most of the 256 CUs idle.
-    const long t128 = (long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
-    const bool waste128 = (p.Cout % 128) != 0 && (p.Cout % 128) <= 64;
-    if (!p.geglu && (waste128 || t128 < 192)) {
-        const long t64 = (long)cdiv(p.M, 64) * cdiv(p.Cout, 64);
-        if (t128 < 96 && t64 >= t128 * 2) return launch_cfg<64, 64, 2, 2>(p, s);
-        return launch_cfg<128, 64, 2, 2>(p, s);
+    switch (pick_tile(p)) {
+        case 2: return launch_cfg<64, 64, 2, 2>(p, s);
+        case 1: return launch_cfg<128, 64, 2, 2>(p, s);
+        default: return launch_cfg<128, 128, 2, 2>(p, s);
     }
-    return launch_cfg<128, 128, 2, 2>(p, s);
 }
 
 }  // namespace sd

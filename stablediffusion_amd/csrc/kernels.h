@@ -26,6 +26,7 @@ struct IGemmParams {
     int geglu;              // 1: y[m, j] = hidden_j * gelu(gate_j), weights interleaved per 64
 };
 int launch_igemm(const IGemmParams& p, hipStream_t s);
+const char* igemm_variant(const IGemmParams& p);   // name of the tile variant launch_igemm picks
 // Rows the packed weight matrix must be padded to (zero rows), so tile loads need no masks.
 constexpr int kWeightRowPad = 256;
 

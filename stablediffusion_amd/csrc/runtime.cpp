@@ -1,6 +1,7 @@
 // Arena, weight store and op wrappers of the denoise engine (host side, HIP runtime only).
 #include "engine.h"
 
+#include <cstdio>
 #include <cstring>
 
 namespace sd {
@@ -240,6 +241,39 @@ int WeightStore::pack_norm(const std::string& prefix, NormW* out) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------- profiler
+namespace {
+struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+void prof_enable(bool on) { g_prof_on = on; }
+bool prof_enabled() { return g_prof_on; }
+void prof_open(hipStream_t s, const char* kernel, double flops, double bytes) {
+    if (!g_prof_on) return;
+    ProfRec r{kernel, flops, bytes, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void prof_close(hipStream_t s) {
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().b, s);
+}
+int prof_collect(std::map<std::string, ProfAgg>* out) {
+    SD_HIP_CHECK(hipDeviceSynchronize());
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ProfAgg& a = (*out)[r.name];
+            a.flops += r.flops; a.bytes += r.bytes; a.ms += ms; a.launches += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return 0;
+}
+
 // -------------------------------------------------------------------------------------------- ops
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride, int up,
              const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad) {
@@ -267,23 +301,42 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
     p.M = N * p.OH * p.OW;
     p.K = (int)w.K;
     p.geglu = geglu;
+    if (prof_enabled()) {
+        const double kreal = (double)w.ks * w.ks * w.cin;
+        const double in_px = (double)N * H * W;
+        prof_open(c.stream, igemm_variant(p), 2.0 * p.M * w.cout * kreal,
+                  2.0 * (in_px * (w.ks == 1 ? (double)w.K : w.cin) + (double)w.cout * w.K +
+                         (double)p.M * (geglu ? w.cout / 2 : w.cout) * (res ? 2 : 1)));
+    }
     c.err = launch_igemm(p, c.stream);
+    prof_close(c.stream);
 }
 
 void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu) {
     float* scratch = c.arena->alloc_f(gn_scratch_floats(N, HW, n.C, G));
     if (c.dry || c.err) return;
+    prof_open(c.stream, "groupnorm(3 kernels)", 0.0, 4.0 * N * HW * n.C);
     c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream);
+    prof_close(c.stream);
 }
 
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps) {
     if (c.dry || c.err) return;
+    prof_open(c.stream, "layernorm_kernel", 0.0, 4.0 * rows * n.C);
     c.err = launch_layernorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, rows, n.C, eps, c.stream);
+    prof_close(c.stream);
 }
 
 void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d) {
     if (c.dry || c.err) return;
+    if (prof_enabled()) {
+        static thread_local char name[32];
+        snprintf(name, sizeof(name), "attn_kernel<%d>", d);
+        prof_open(c.stream, name, 4.0 * B * heads * (double)Tq * Tk * d,
+                  2.0 * B * heads * d * (2.0 * Tq + 2.0 * Tk));
+    }
     c.err = launch_attention(q.p, k.p, v.p, out.p, B, Tq, Tk, heads, d, q.ld, k.ld, v.ld, out.ld, c.stream);
+    prof_close(c.stream);
 }
 
 }  // namespace sd

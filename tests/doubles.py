@@ -1,0 +1,46 @@
+"""Test doubles: oracle-backed stand-ins for the `.base` / `.vae` slots, so the host-side pipeline,
+scheduler and sharding logic can be exercised on CPU.  Test infrastructure only -- the product
+shims (stablediffusion_amd.models) never fall back to these."""
+from types import SimpleNamespace
+
+import torch
+
+from oracle import unet_ref, vae_ref
+
+
+class OracleUNet:
+    def __init__(self, cfg, sd):
+        self.cfg, self.sd = cfg, sd
+        self.config = SimpleNamespace(**cfg.to_dict())
+        self.dtype = torch.float32
+        if cfg.addition_embed_type == "text_time":
+            self.add_embedding = SimpleNamespace(
+                linear_1=SimpleNamespace(in_features=cfg.projection_class_embeddings_input_dim))
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, sample, t, ehs, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=False):
+        return (unet_ref.unet_forward(self.cfg, self.sd, sample.float(), t, ehs.float(), added_cond_kwargs),)
+
+
+class OracleVAE:
+    def __init__(self, cfg, sd):
+        self.cfg, self.sd = cfg, sd
+        self.config = SimpleNamespace(**cfg.to_dict())
+        self.dtype = torch.float32
+
+    def to(self, *a, **k):
+        return self
+
+    def decode(self, z, return_dict=False):
+        return (vae_ref.vae_decode(self.cfg, self.sd, z.float()),)
+
+    def encode(self, x):
+        mom = vae_ref.vae_encode_moments(self.cfg, self.sd, x.float())
+        mean, logvar = mom.chunk(2, dim=1)
+        std = torch.exp(0.5 * logvar.clamp(-30, 20))
+        dist = SimpleNamespace(
+            sample=lambda generator=None: mean + std * torch.randn(mean.shape, generator=generator),
+            mode=lambda: mean)
+        return SimpleNamespace(latent_dist=dist)
