@@ -150,6 +150,10 @@ typedef struct sd_prof_entry {
 int sd_prof_enable(int on);
 int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries);
 
+/* Tuner / test hook: force the LDS-DMA conv kernel's tile variant (0..5) and split-K factor for
+ * every following launch; variant -1 restores the built-in per-shape choice. */
+int sd_igemm_force(int variant, int splits);
+
 /* -- single operators, exported for the parity tests (tests/test_ops_gpu.py) ----------------- */
 /* Implicit-GEMM convolution / linear on NHWC f16:
  *   y[n,oh,ow,co] = bias[co] + rowadd[n,co] + res[n,oh,ow,co]
@@ -159,6 +163,11 @@ int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries);
 int sd_op_conv2d(const void* x_nhwc, const void* w_oihw, const void* bias, const void* rowadd,
                  const void* res_nhwc, void* y_nhwc, int N, int H, int W, int Cin, int Cout,
                  int ksize, int stride, int upsample2x, int geglu, void* stream);
+/* Same operator, timed: `iters` back-to-back launches bracketed by HIP events on `stream`
+ * (after two warm-up launches); used by tools/tune_igemm.py to pick tile variants per shape. */
+int sd_bench_conv2d(const void* x_nhwc, const void* w_oihw, void* y_nhwc, int N, int H, int W, int Cin,
+                    int Cout, int ksize, int stride, int upsample2x, int geglu, int iters,
+                    float* ms_per_launch, void* stream);
 /* GroupNorm (+ optional SiLU) on NHWC f16, fp32 statistics. */
 int sd_op_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
                     int N, int HW, int C, int groups, float eps, int silu, void* stream);

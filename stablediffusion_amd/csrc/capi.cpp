@@ -140,6 +140,9 @@ int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float 
                            guidance_scale, c_x, c_eps, static_cast<hipStream_t>(stream));
 }
 
+// ------------------------------------------------------------------------------------------ tuning
+int sd_igemm_force(int variant, int splits) { igemm2_force(variant, splits); return SD_OK; }
+
 // --------------------------------------------------------------------------------------- profiling
 int sd_prof_enable(int on) { prof_enable(on != 0); return SD_OK; }
 int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries) {
@@ -159,10 +162,10 @@ int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries) {
 }
 
 // ------------------------------------------------------------------------- single-operator entries
-// Test-path only: packs the weight on every call (allocation + sync); never used by the models.
-int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
-                 void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int upsample2x,
-                 int geglu, void* stream) {
+// Test / tuner path only: packs the weight on every call (allocation + sync); never used by the models.
+static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
+                       void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int upsample2x,
+                       int geglu, void* stream, int iters, float* ms_out) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long K = (long)ksize * ksize * Cin;
     if (K % 64 != 0 || Cin % 64 != 0) { set_error("sd_op_conv2d: Cin must be a multiple of 64"); return SD_ERR_INVALID; }
@@ -194,6 +197,7 @@ int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const 
         (void)hipFree(wp); (void)hipFree(bp);
         wp = wg; bp = bg;
     }
+    float* partial = nullptr;
     if (!rc) {
         IGemmParams p;
         p.x = static_cast<const half_t*>(x); p.ldx = Cin;
@@ -208,12 +212,45 @@ int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const 
         p.Cout = Cout; p.M = N * p.OH * p.OW; p.K = (int)K; p.geglu = geglu;
         const int ocols = geglu ? Cout / 2 : Cout;
         p.ldres = ocols; p.y = static_cast<half_t*>(y); p.ldy = ocols;
-        rc = launch_igemm(p, s);
+        const bool v2 = igemm2_supported(p);
+        if (v2) {
+            const long pf = igemm2_partial_floats(p);
+            if (pf > 0) SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&partial), (size_t)pf * sizeof(float)));
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ms_out) { SD_HIP_CHECK(hipEventCreate(&e0)); SD_HIP_CHECK(hipEventCreate(&e1)); }
+        for (int it = 0; it < iters + (ms_out ? 2 : 0) && !rc; ++it) {
+            if (ms_out && it == 2) SD_HIP_CHECK(hipEventRecord(e0, s));     // two warm-up launches
+            rc = v2 ? launch_igemm2(p, partial, s) : launch_igemm(p, s);
+        }
+        if (ms_out && !rc) {
+            SD_HIP_CHECK(hipEventRecord(e1, s));
+            SD_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            *ms_out = ms / (float)iters;
+        }
+        if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     }
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(wp); (void)hipFree(bp);
+    if (partial) (void)hipFree(partial);
     if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
     return rc;
+}
+
+int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
+                 void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int upsample2x,
+                 int geglu, void* stream) {
+    return conv2d_impl(x, w_oihw, bias_f32, rowadd_f32, res, y, N, H, W, Cin, Cout, ksize, stride, upsample2x, geglu,
+                       stream, 1, nullptr);
+}
+
+int sd_bench_conv2d(const void* x, const void* w_oihw, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
+                    int stride, int upsample2x, int geglu, int iters, float* ms_per_launch, void* stream) {
+    if (iters < 1 || !ms_per_launch) { set_error("sd_bench_conv2d: bad arguments"); return SD_ERR_INVALID; }
+    return conv2d_impl(x, w_oihw, nullptr, nullptr, nullptr, y, N, H, W, Cin, Cout, ksize, stride, upsample2x, geglu,
+                       stream, iters, ms_per_launch);
 }
 
 int sd_op_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int N, int HW, int C,

@@ -1,0 +1,424 @@
+// Implicit-GEMM convolution / linear, LDS-DMA pipeline (gfx950 / CDNA4).
+//
+// Same contract as igemm.hip (IGemmParams), different data path -- the one the MI355X wants:
+//   * both operand tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging
+//     VGPRs, no ds_write pass.  One wave-instruction fills 8 tile rows x 128 B; the XOR swizzle that
+//     makes the ds_read_b128 fragment reads conflict-free is applied on the per-lane SOURCE address
+//     (the LDS image of a DMA is lane-linear).
+//   * the im2col gather, zero padding, stride 2, nearest-2x upsample and the ragged last M tile
+//     are all address arithmetic on the DMA's per-lane byte offset: an out-of-image tap uses an
+//     out-of-range buffer offset, for which the hardware writes zeros into LDS.
+//   * ring of STAGES LDS buffers, prefetch distance STAGES-1, ONE raw s_barrier per 64-deep K slab
+//     and a COUNTED s_waitcnt vmcnt(N) so the next slab's DMA stays in flight across the barrier.
+//   * optional split-K (gridDim.y): every z-slice writes an fp32 partial slab; the epilogue kernel
+//     splitk_epilogue_kernel reduces the slabs in a fixed order (deterministic) and applies
+//     bias / time-embedding row add / residual / GEGLU.
+// Tile variants (BM x BN, waves, stages) are chosen per shape by pick_variant().
+#include "kernels.h"
+
+namespace sd {
+namespace {
+
+constexpr int BK = 64;
+constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any buffer -> DMA writes zeros
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmParams p, float* partial,
+                                                                      int k_tiles_per_split) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NT = 64 * NW;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;     // DMA instructions per wave per slab
+    constexpr int LPW = A_PW + B_PW;
+    constexpr int STAGE_HALVES = (BM + BN) * BK;
+    constexpr int LDC = BN + 8;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA rows must divide over the waves");
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be MFMA-shaped");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+
+    // The body is device-only: clang's host pass cannot type-check the gfx950 LDS-DMA builtin
+    // (16-byte size) and would silently drop the kernel's host stub.
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* ring = reinterpret_cast<half_t*>(smem);
+    half_t* sC = reinterpret_cast<half_t*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int nk_total = p.K / BK;
+    const int kt_begin = split * k_tiles_per_split;
+    int nk = nk_total - kt_begin;
+    if (nk > k_tiles_per_split) nk = k_tiles_per_split;
+
+    // ---- DMA descriptors (wave-uniform) ----
+    const long x_bytes = (long)p.N * p.H * p.W * p.ldx * 2;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, (int)x_bytes, 0x00020000);
+    const long wrows = ((long)p.Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, (int)(wrows * p.K * 2), 0x00020000);
+
+    // ---- per-lane source coordinates: lane -> (row = 8*instr + lane/8, chunk = (lane%8) ^ (lane/8)) ----
+    const int lrow = lane >> 3;
+    const int chunk = (lane & 7) ^ lrow;
+    const int OHW = p.OH * p.OW;
+    const unsigned IH = (unsigned)(p.H << p.up), IW = (unsigned)(p.W << p.up);
+    int a_ih[A_PW], a_iw[A_PW];   // top-left input coordinate of the row's pixel; rows >= M get a
+                                  // coordinate that can never pass the unsigned bounds check
+    unsigned a_base[A_PW];        // byte offset of (n, 0, 0, chunk), or of the row itself (pointwise)
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int m = m0 + (wave * A_PW + j) * 8 + lrow;
+        const bool okm = m < p.M;
+        const int mm = okm ? m : 0;
+        if (PW) {
+            a_ih[j] = okm ? 0 : -(1 << 28); a_iw[j] = 0;
+            a_base[j] = (unsigned)(((long)mm * p.ldx + chunk * 8) * 2);
+        } else {
+            const int n = mm / OHW;
+            const int rem = mm - n * OHW;
+            const int oh = rem / p.OW;
+            const int ow = rem - oh * p.OW;
+            a_ih[j] = okm ? oh * p.stride - p.pad : -(1 << 28);
+            a_iw[j] = ow * p.stride - p.pad;
+            a_base[j] = (unsigned)(((long)n * p.H * p.W * p.ldx + chunk * 8) * 2);
+        }
+    }
+    unsigned b_off[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j)
+        b_off[j] = (unsigned)((((long)(n0 + (wave * B_PW + j) * 8 + lrow)) * p.K + chunk * 8) * 2);
+
+    // tap state of the NEXT slab to issue
+    int k0 = kt_begin * BK;
+    int tap = k0 / p.Cin;
+    int ci0 = k0 - tap * p.Cin;
+    int kh = tap / p.KS, kw = tap - kh * p.KS;
+    const unsigned row_bytes = (unsigned)(p.ldx * 2);
+
+    auto issue = [&](int slot) {
+        half_t* sa = ring + slot * STAGE_HALVES;
+        half_t* sb = sa + BM * BK;
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            unsigned voff;
+            if (PW) {
+                voff = a_ih[j] >= 0 ? a_base[j] + (unsigned)(k0 * 2) : kOOB;
+            } else {
+                const int ih = a_ih[j] + kh, iw = a_iw[j] + kw;
+                const bool ok = ((unsigned)ih < IH) & ((unsigned)iw < IW);   // negative -> huge unsigned
+                const unsigned off = a_base[j] + (unsigned)((ih >> p.up) * p.W + (iw >> p.up)) * row_bytes +
+                                     (unsigned)(ci0 * 2);
+                voff = ok ? off : kOOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rx, (__attribute__((address_space(3))) void*)(sa + (wave * A_PW + j) * 512), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rw, (__attribute__((address_space(3))) void*)(sb + (wave * B_PW + j) * 512), 16,
+                b_off[j] + (unsigned)(k0 * 2), 0, 0, 0);
+        k0 += BK;
+        ci0 += BK;
+        if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
+    };
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int D = STAGES - 1;       // prefetch distance
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nk) issue(s);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt must have landed; at most D-1 younger stages may stay in flight
+        if (D == 2 && kt + 1 < nk) wait_vmcnt<LPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);   // (kt + D) % STAGES == (kt - 1) % STAGES
+        const half_t* cA = ring + slot * STAGE_HALVES;
+        const half_t* cB = cA + BM * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 fa[TM], fb[TN];
+            const int ch = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * WTM + i * 16 + fr;
+                fa[i] = *reinterpret_cast<const h8*>(cA + r * BK + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * WTN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const h8*>(cB + r * BK + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+    }
+
+    // ---- split-K: raw fp32 partials, reduced by splitk_epilogue_kernel ----
+    if (partial) {
+        float* dst = partial + (long)split * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + fq * 4;
+                if (m < p.M && n < p.Cout) *reinterpret_cast<f4*>(dst + (long)m * p.Cout + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+
+    // ---- fused epilogue through LDS (same as igemm.hip) ----
+    __syncthreads();     // every wave is done with the ring before it is overlaid
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pr = wm * WTM + i * 16 + fr;
+        const int m = m0 + pr;
+        int nimg = 0;
+        if (p.rowadd) nimg = (m < p.M ? m : 0) / OHW;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * WTN + j * 16 + fq * 4;
+            f4 v = acc[i][j];
+            if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + n0 + col);
+            if (p.rowadd && n0 + col < p.Cout)
+                v += *reinterpret_cast<const f4*>(p.rowadd + (long)nimg * p.rowadd_ld + n0 + col);
+            h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
+        }
+    }
+    __syncthreads();
+
+    if (p.geglu) {
+        constexpr int OCH = BN / 16;
+        const int out_n0 = n0 >> 1;
+        for (int idx = tid; idx < BM * OCH; idx += NT) {
+            const int r = idx / OCH, oc = (idx - r * OCH) * 8;
+            const int m = m0 + r;
+            const int hcol = (oc >> 6) * 128 + (oc & 63);
+            if (m < p.M && n0 + hcol < p.Cout) {
+                const h8 hv = *reinterpret_cast<const h8*>(sC + r * LDC + hcol);
+                const h8 gv = *reinterpret_cast<const h8*>(sC + r * LDC + hcol + 64);
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)hv[e] * gelu_erf_f((float)gv[e]));
+                *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + out_n0 + oc) = o;
+            }
+        }
+        return;
+    }
+    constexpr int CH = BN / 8;
+    for (int idx = tid; idx < BM * CH; idx += NT) {
+        const int r = idx / CH, c = (idx - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c;
+        if (m < p.M && n < p.Cout) {
+            h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
+            if (p.res) {
+                const h8 rv = *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + n) = v;
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// Fixed-order reduction of split-K partial slabs + the fused epilogue (bias, rowadd, residual).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, const float* __restrict__ partial,
+                                                              int splits) {
+    const long total = (long)p.M * (p.Cout / 8);
+    const long slab = (long)p.M * p.Cout;
+    const int OHW = p.OH * p.OW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / (p.Cout / 8);
+        const int n = (int)(idx - m * (p.Cout / 8)) * 8;
+        float v[8];
+        const float* src = partial + m * p.Cout + n;
+        const f4 a0 = *reinterpret_cast<const f4*>(src), a1 = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[e + 4] = a1[e]; }
+        for (int s = 1; s < splits; ++s) {
+            const f4 b0 = *reinterpret_cast<const f4*>(src + s * slab), b1 = *reinterpret_cast<const f4*>(src + s * slab + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+        }
+        if (p.rowadd) {
+            const float* ra = p.rowadd + (m / OHW) * p.rowadd_ld + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ra[e];
+        }
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+        if (p.res) {
+            const h8 rv = *reinterpret_cast<const h8*>(p.res + m * p.ldres + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+        }
+        *reinterpret_cast<h8*>(p.y + m * p.ldy + n) = o;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool PW>
+int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
+    constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
+    constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(half_t);
+    constexpr size_t lds = ring > epi ? ring : epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, STAGES, PW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
+    const int nk = p.K / BK;
+    const int per = cdiv(nk, splits);
+    const int eff_splits = cdiv(nk, per);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
+                       p, eff_splits > 1 ? partial : nullptr, per);
+    SD_HIP_CHECK(hipGetLastError());
+    if (eff_splits > 1) {
+        const long total = (long)p.M * (p.Cout / 8);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p, partial, eff_splits);
+        SD_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch_v2(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
+    if (p.KS == 1 && p.stride == 1 && p.up == 0) return launch_v2p<BM, BN, WM, WN, STAGES, true>(p, partial, splits, s);
+    return launch_v2p<BM, BN, WM, WN, STAGES, false>(p, partial, splits, s);
+}
+
+int g_force_variant = -1;
+int g_force_splits = 0;
+
+}  // namespace
+
+// Variant ids (also used by the tuner in tests/tools): keep in sync with kIgemm2Names.
+//   0: 256x128 8 waves 3 stages   1: 128x128 4 waves 2 stages   2: 128x160 4 waves 2 stages
+//   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
+static const char* kIgemm2Names[] = {"igemm2<256,128,s3>", "igemm2<128,128,s2>", "igemm2<128,160,s2>",
+                                     "igemm2<128,64,s2>",  "igemm2<64,64,s2>",   "igemm2<256,160,s3>"};
+constexpr int kNumVariants = 6;
+
+void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
+
+bool igemm2_supported(const IGemmParams& p) {
+    const long x_bytes = (long)p.N * p.H * p.W * p.ldx * 2;
+    const long wrows = ((long)p.Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    return p.K % BK == 0 && p.Cin % BK == 0 && (p.Cout % 8) == 0 && x_bytes < (1L << 31) &&
+           wrows * p.K * 2 < (1L << 31) && (!p.geglu || p.Cout % 128 == 0);
+}
+
+static void tile_dims(int v, int* bm, int* bn) {
+    static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}};
+    *bm = dims[v][0]; *bn = dims[v][1];
+}
+
+// Per-shape choices measured on MI355X by tools/tune_igemm.py (profiles/tune/*.json).
+struct TunedEntry { int M, N, K, ks, stride, up, geglu, variant, splits; };
+static const TunedEntry kTuned[] = {
+#include "igemm2_table.inc"
+};
+
+// Tile variant + split-K for a problem: the tuned table when the shape is in it, otherwise a rule
+// distilled from the same measurements: 128x160 tiles whenever Cout is a multiple of 160 (every
+// UNet / VAE width is), 128x128 otherwise; narrow tiles for small, shallow problems; split-K until
+// about two blocks per CU (512) are in flight, keeping >= 12 K-slabs per slice.
+void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
+    if (g_force_variant >= 0) {
+        *variant = g_force_variant;
+        *splits = g_force_splits > 0 ? g_force_splits : 1;
+        if (p.geglu && (*variant == 2 || *variant == 5 || *variant == 3 || *variant == 4)) *variant = 1;
+        if (p.geglu) *splits = 1;
+        return;
+    }
+    for (const TunedEntry& e : kTuned)
+        if (e.M == p.M && e.N == p.Cout && e.K == p.K && e.ks == p.KS && e.stride == p.stride && e.up == p.up &&
+            e.geglu == p.geglu) {
+            *variant = e.variant; *splits = e.splits;
+            return;
+        }
+    const int nk = p.K / BK;
+    int v;
+    if (p.geglu) v = (long)cdiv(p.M, 256) * cdiv(p.Cout, 128) >= 512 ? 0 : 1;
+    else if (p.Cout % 160 == 0) v = 2;
+    else v = 1;
+    int bm, bn;
+    tile_dims(v, &bm, &bn);
+    long tiles = (long)cdiv(p.M, bm) * cdiv(p.Cout, bn);
+    if (!p.geglu && tiles < 256 && nk <= 40) {          // small and shallow: narrow tiles fill more CUs
+        v = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64) >= 256 ? 3 : 4;
+        tile_dims(v, &bm, &bn);
+        tiles = (long)cdiv(p.M, bm) * cdiv(p.Cout, bn);
+    }
+    int sp = 1;
+    if (!p.geglu && tiles < 384 && nk >= 24) {
+        sp = (int)((512 + tiles / 2) / tiles);
+        if (sp > 8) sp = 8;
+        while (sp > 1 && nk / sp < 12) --sp;
+    }
+    *variant = v;
+    *splits = sp;
+}
+
+const char* igemm2_name(int variant) { return kIgemm2Names[variant]; }
+
+long igemm2_partial_floats(const IGemmParams& p) {
+    int v, sp;
+    igemm2_pick(p, &v, &sp);
+    return sp > 1 ? (long)sp * p.M * p.Cout : 0;
+}
+
+int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
+    int v, sp;
+    igemm2_pick(p, &v, &sp);
+    if (sp > 1 && !partial) sp = 1;
+    switch (v) {
+        case 0: return launch_v2<256, 128, 4, 2, 3>(p, partial, sp, s);
+        case 1: return launch_v2<128, 128, 2, 2, 2>(p, partial, sp, s);
+        case 2: return launch_v2<128, 160, 2, 2, 2>(p, partial, sp, s);
+        case 3: return launch_v2<128, 64, 2, 2, 2>(p, partial, sp, s);
+        case 4: return launch_v2<64, 64, 2, 2, 2>(p, partial, sp, s);
+        case 5: return launch_v2<256, 160, 4, 1, 3>(p, partial, sp, s);
+        default: set_error("igemm2: bad variant"); return 1;
+    }
+}
+
+}  // namespace sd

@@ -27,6 +27,13 @@ struct IGemmParams {
 };
 int launch_igemm(const IGemmParams& p, hipStream_t s);
 const char* igemm_variant(const IGemmParams& p);   // name of the tile variant launch_igemm picks
+// LDS-DMA pipeline variants (igemm2.hip); falls back to launch_igemm when !igemm2_supported().
+bool igemm2_supported(const IGemmParams& p);
+void igemm2_pick(const IGemmParams& p, int* variant, int* splits);
+const char* igemm2_name(int variant);
+long igemm2_partial_floats(const IGemmParams& p);      // fp32 workspace needed for split-K (0 if none)
+int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s);
+void igemm2_force(int variant, int splits);            // tuner / tests: -1 restores the heuristic
 // Rows the packed weight matrix must be padded to (zero rows), so tile loads need no masks.
 constexpr int kWeightRowPad = 256;
 

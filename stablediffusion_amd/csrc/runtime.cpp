@@ -277,7 +277,6 @@ int prof_collect(std::map<std::string, ProfAgg>* out) {
 // -------------------------------------------------------------------------------------------- ops
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride, int up,
              const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad) {
-    if (c.dry || c.err) return;
     IGemmParams p;
     p.x = x.p; p.ldx = x.ld;
     p.w = w.w; p.bias = w.bias;
@@ -301,14 +300,29 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
     p.M = N * p.OH * p.OW;
     p.K = (int)w.K;
     p.geglu = geglu;
+    const bool v2 = igemm2_supported(p);
+    float* partial = nullptr;
+    if (v2) {
+        const long pf = igemm2_partial_floats(p);
+        if (pf > 0) partial = c.arena->alloc_f(pf);
+    }
+    if (c.dry || c.err) return;
     if (prof_enabled()) {
         const double kreal = (double)w.ks * w.ks * w.cin;
         const double in_px = (double)N * H * W;
-        prof_open(c.stream, igemm_variant(p), 2.0 * p.M * w.cout * kreal,
+        const char* name = igemm_variant(p);
+        static thread_local char nbuf[48];
+        if (v2) {
+            int var, sp;
+            igemm2_pick(p, &var, &sp);
+            snprintf(nbuf, sizeof(nbuf), "%s%s", igemm2_name(var), sp > 1 ? "+splitK" : "");
+            name = nbuf;
+        }
+        prof_open(c.stream, name, 2.0 * p.M * w.cout * kreal,
                   2.0 * (in_px * (w.ks == 1 ? (double)w.K : w.cin) + (double)w.cout * w.K +
                          (double)p.M * (geglu ? w.cout / 2 : w.cout) * (res ? 2 : 1)));
     }
-    c.err = launch_igemm(p, c.stream);
+    c.err = v2 ? launch_igemm2(p, partial, c.stream) : launch_igemm(p, c.stream);
     prof_close(c.stream);
 }
 

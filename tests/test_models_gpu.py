@@ -57,7 +57,9 @@ def test_unet_per_sample_timesteps_and_determinism(engine_lib, tiny_unet):
 
 
 def test_unet_batch_independence(engine_lib, tiny_unet):
-    """Sharding property: a sample's result does not depend on its batch mates."""
+    """Sharding property: a sample's result does not depend on its batch mates.
+    Tile shape / split-K are picked per problem size, so a different batch size may change the fp32
+    summation order: equal to fp16 rounding (rel-L2 < 1e-3), and bitwise for equal shapes."""
     cfg, sd, net = tiny_unet
     g = torch.Generator().manual_seed(6)
     x = torch.randn(4, 4, 16, 16, generator=g).half().cuda()
@@ -65,7 +67,10 @@ def test_unet_batch_independence(engine_lib, tiny_unet):
     full = net(x, torch.tensor(301.0), ehs)[0]
     lo = net(x[:2], torch.tensor(301.0), ehs[:2])[0]
     hi = net(x[2:], torch.tensor(301.0), ehs[2:])[0]
-    assert torch.equal(full, torch.cat([lo, hi]))
+    assert rel_l2(full, torch.cat([lo, hi])) < 1e-3
+    assert torch.equal(lo, net(x[:2], torch.tensor(301.0), ehs[:2])[0])
+    swapped = net(torch.cat([x[2:], x[:2]]), torch.tensor(301.0), torch.cat([ehs[2:], ehs[:2]]))[0]
+    assert torch.equal(full, torch.cat([swapped[2:], swapped[:2]]))     # position in the batch is irrelevant
 
 
 def test_unet_sdxl_style(engine_lib):

@@ -72,6 +72,20 @@ def test_conv2d(engine_lib, case):
     assert rel_l2(got, ref) < 2e-3            # fp16 output rounding: ~5e-4 relative
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv2d_every_tile_variant(engine_lib, variant, splits):
+    """Every LDS-DMA tile variant (and the split-K reduction) on a 3x3, a strided, an upsampled and a
+    pointwise problem with ragged M / N; results must match regardless of the tile chosen."""
+    engine_lib.sd_igemm_force(variant, splits)
+    try:
+        for case in [(2, 12, 20, 128, 320, 3, 1, 0, True), (1, 16, 16, 64, 192, 3, 2, 0, True),
+                     (1, 9, 7, 128, 72, 3, 1, 1, True), (2, 17, 5, 256, 200, 1, 1, 0, True)]:
+            test_conv2d(engine_lib, case)
+    finally:
+        engine_lib.sd_igemm_force(-1, 0)
+
+
 def test_conv_geglu(engine_lib):
     """Linear(C, 8C) + GEGLU epilogue: hidden * gelu(gate) with the 64-row interleaved packing."""
     g = torch.Generator().manual_seed(7)
