@@ -234,6 +234,7 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                       "traffic": None, "launches_per_unet_forward": launches,
                                       "avg_launch_us": round(ms / launches * 1e3, 2)}
+            result["unet_forward_profiled_sum_ms"] = round(sum(r[3] for r in urows), 3)
             result["kernels_unet_forward"] = [
                 {"kernel": k, "ms": round(m, 3), "launches": l,
                  "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,

@@ -1,7 +1,7 @@
 // Flash-style attention for gfx950 (CDNA4, wave64): out = softmax(q k^T / sqrt(d)) v, fp16 in/out,
-// fp32 scores / running max / running sum / output accumulators; the T x T score matrix is never
-// materialised.  Replaces F.scaled_dot_product_attention under diffusers' AttnProcessor2_0 for the
-// UNet self/cross attention and the VAE mid-block attention (call sites
+// fp32 scores / running max / output accumulators; the T x T score matrix is never materialised.
+// Replaces F.scaled_dot_product_attention under diffusers' AttnProcessor2_0 for the UNet self/cross
+// attention and the VAE mid-block attention (call sites
 // /root/reference/pipelines/sd_unified_pipeline.py:475-482, :523).
 //
 // MI355X-specific structure:
@@ -9,12 +9,18 @@
 //       S^T = K Q^T   (MFMA A = K rows from LDS, B = Q fragments held in registers)
 //       O^T = V^T P^T (MFMA A = V^T fetched with ds_read_b64_tr_b16 from a row-major V tile,
 //                      B = P^T taken straight from the S^T accumulators -- no LDS round trip)
-//     A 16x16 accumulator tile has the query on lane&15 and 4 keys per lane-group, which is
-//     exactly the k-slot layout of the B operand once the V^T fragment is fetched in the same
-//     permuted key order.
+//   * small head dims (SD1.5 level 0: d = 40) are VALU-bound, not MFMA-bound, so the softmax is
+//     stripped to ~4 VALU ops per score: max on the raw scores (v_max3), one FMA folding the
+//     1/sqrt(d)*log2(e) scale and the running max, a raw v_exp_f32, and v_cvt_pkrtz_f16_f32 packing
+//     two probabilities per instruction.  Where the head dim leaves spare rows in the last 16-row
+//     PV tile (d = 40 -> 48) a column of ones is appended to V, so the softmax denominator falls
+//     out of the PV MFMA for free; the truncation bias of pkrtz then cancels in the normalisation.
+//   * the output rescale by exp2(m_old - m_new) is skipped (wave-uniformly) while the running max
+//     grows by less than 2^8 -- probabilities stay below 256, well inside fp16.
 //   * K / V tiles of 64 keys in LDS with row strides that are odd multiples of 32 bytes:
-//     conflict-free for both ds_read_b128 fragment reads and the transposed reads.
-//   * head dims 40 / 80 / 160 (SD1.5), 64 (SDXL), 512 (VAE), 32 (test configs); the QK^T
+//     conflict-free for both ds_read_b128 fragment reads and the transposed reads; the next tile's
+//     global loads are issued before the current tile is multiplied (register-staged prefetch).
+//   * head dims 40 / 80 / 160 (SD1.5), 64 (SDXL), 512 (VAE), 32 / 128 (test configs); the QK^T
 //     contraction is zero-padded to a multiple of 32, the PV row tiles to a multiple of 16.
 #include "kernels.h"
 
@@ -22,8 +28,15 @@ namespace sd {
 namespace {
 
 constexpr int KT = 64;  // keys per tile
+constexpr float kRescaleThreshold = 8.0f;   // log2 units
 
 constexpr int odd32_bytes(int bytes) { return ((((bytes + 31) / 32) | 1)) * 32; }
+
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_rtz(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
 
 template <int D, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
@@ -37,7 +50,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     constexpr int DT = (D + 15) / 16;
     constexpr int KSTR = odd32_bytes(DK * 2) / 2;        // halves
     constexpr int VSTR = odd32_bytes(DT * 16 * 2) / 2;   // halves
-    constexpr int KCH = KSTR / 8, VCH = VSTR / 8;        // 16-byte chunks per LDS row
+    constexpr int CH = D / 8;                            // real 16-byte chunks per row
+    constexpr int NCH = KT * CH;                         // chunk slots per tile (K and V alike)
+    constexpr int LIT = (NCH + 255) / 256;               // staging iterations per thread
+    constexpr bool ONES = DT * 16 > D;                   // spare PV rows -> denominator via MFMA
+    constexpr bool PREFETCH = D <= 160;                  // register-staged prefetch of the next tile
     constexpr int QB = 64 * QT;                          // queries per block
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,6 +70,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     const half_t* qb = q + (long)b * Tq * ldq + h * D;
     const half_t* kb = k + (long)b * Tk * ldk + h * D;
     const half_t* vb = v + (long)b * Tk * ldv + h * D;
+
+    // ---- one-time LDS padding: K columns [D, DK) = 0 (the Q pad is zero too), V columns
+    //      [D, VSTR) = 0 with a column of ones at D when the denominator rides on the PV MFMA ----
+    for (int idx = tid; idx < KT * (KSTR - D); idx += 256) {
+        const int r = idx / (KSTR - D), c = D + idx - r * (KSTR - D);
+        sK[r * KSTR + c] = (half_t)0.f;
+    }
+    for (int idx = tid; idx < KT * (VSTR - D); idx += 256) {
+        const int r = idx / (VSTR - D), c = D + idx - r * (VSTR - D);
+        sV[r * VSTR + c] = (ONES && c == D) ? (half_t)1.f : (half_t)0.f;
+    }
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[query fr][32 ks + 8 fq .. +8]
     h8 qf[QT][KS];
@@ -73,26 +101,56 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int t = 0; t < QT; ++t) o[i][t] = f4{0.f, 0.f, 0.f, 0.f};
-    float mrun[QT], lrun[QT];
+    float mrun[QT], lrun[QT];     // running max in the scaled log2 domain; partial row sums (!ONES)
 #pragma unroll
     for (int t = 0; t < QT; ++t) { mrun[t] = -INFINITY; lrun[t] = 0.f; }
 
+    // staging registers (next tile)
+    h8 kreg[PREFETCH ? LIT : 1], vreg[PREFETCH ? LIT : 1];
+    auto load_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < LIT; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CH, c = (idx - r * CH) * 8;
+            h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < NCH && kt0 + r < Tk) {
+                kv = *reinterpret_cast<const h8*>(kb + (long)(kt0 + r) * ldk + c);
+                vv = *reinterpret_cast<const h8*>(vb + (long)(kt0 + r) * ldv + c);
+            }
+            kreg[i] = kv; vreg[i] = vv;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < LIT; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CH, c = (idx - r * CH) * 8;
+            if (idx < NCH) {
+                *reinterpret_cast<h8*>(sK + r * KSTR + c) = kreg[i];
+                *reinterpret_cast<h8*>(sV + r * VSTR + c) = vreg[i];
+            }
+        }
+    };
+    if (PREFETCH) load_tile(0);
+
     for (int kt0 = 0; kt0 < Tk; kt0 += KT) {
-        __syncthreads();
-        // ---- stage K and V tiles (zero-filled padding) ----
-        for (int idx = tid; idx < KT * KCH; idx += 256) {
-            const int r = idx / KCH, c = (idx - r * KCH) * 8;
-            h8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt0 + r < Tk && c < D) val = *reinterpret_cast<const h8*>(kb + (long)(kt0 + r) * ldk + c);
-            *reinterpret_cast<h8*>(sK + r * KSTR + c) = val;
+        __syncthreads();                       // previous tile fully consumed (and padding written)
+        if (PREFETCH) {
+            store_tile();
+        } else {
+            for (int idx = tid; idx < NCH; idx += 256) {
+                const int r = idx / CH, c = (idx - r * CH) * 8;
+                h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kt0 + r < Tk) {
+                    kv = *reinterpret_cast<const h8*>(kb + (long)(kt0 + r) * ldk + c);
+                    vv = *reinterpret_cast<const h8*>(vb + (long)(kt0 + r) * ldv + c);
+                }
+                *reinterpret_cast<h8*>(sK + r * KSTR + c) = kv;
+                *reinterpret_cast<h8*>(sV + r * VSTR + c) = vv;
+            }
         }
-        for (int idx = tid; idx < KT * VCH; idx += 256) {
-            const int r = idx / VCH, c = (idx - r * VCH) * 8;
-            h8 val = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt0 + r < Tk && c < D) val = *reinterpret_cast<const h8*>(vb + (long)(kt0 + r) * ldv + c);
-            *reinterpret_cast<h8*>(sV + r * VSTR + c) = val;
-        }
         __syncthreads();
+        if (PREFETCH && kt0 + KT < Tk) load_tile(kt0 + KT);    // in flight while this tile is multiplied
 
         // ---- S^T = K Q^T : 4 key subtiles x QT query subtiles ----
         f4 s[4][QT];
@@ -110,39 +168,60 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                     s[ksub][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[ksub][t], 0, 0, 0);
             }
         }
+        if (kt0 + KT > Tk) {                   // ragged last tile: keys >= Tk never win and weigh 0
+#pragma unroll
+            for (int ksub = 0; ksub < 4; ++ksub)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (kt0 + ksub * 16 + fq * 4 + j >= Tk) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) s[ksub][t][j] = -INFINITY;
+                    }
+        }
 
-        // ---- online softmax (per query = per lane column), scores scaled into log2 domain ----
-        const bool tail = kt0 + KT > Tk;
-        h8 pf[QT][2];
+        // ---- online softmax: per query = per lane column ----
+        unsigned pf[QT][2][4];                 // P^T as packed fp16 pairs: [k-step of 32 keys][4 dwords]
+        bool grow = false;
+        float mx[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = -INFINITY;
+            float m = -INFINITY;
 #pragma unroll
             for (int ksub = 0; ksub < 4; ++ksub)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float val = s[ksub][t][j] * scale_log2e;
-                    if (tail && kt0 + ksub * 16 + fq * 4 + j >= Tk) val = -INFINITY;
-                    s[ksub][t][j] = val;
-                    mx = fmaxf(mx, val);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[t], mx);
-            const float alpha = exp2f(mrun[t] - mnew);
-            mrun[t] = mnew;
+                for (int j = 0; j < 4; ++j) m = fmaxf(m, s[ksub][t][j]);
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            mx[t] = m * scale_log2e;
+            grow |= mx[t] > mrun[t] + kRescaleThreshold;
+        }
+        if (__any(grow)) {                     // wave-uniform: rescale everything kept at the old max
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float mnew = fmaxf(mrun[t], mx[t]);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
+                mrun[t] = mnew;
+                lrun[t] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) o[i][t] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float nm = -mrun[t];
             float psum = 0.f;
 #pragma unroll
-            for (int ksub = 0; ksub < 4; ++ksub)
+            for (int ksub = 0; ksub < 4; ++ksub) {
+                float p[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float pv = exp2f(s[ksub][t][j] - mnew);
-                    psum += pv;
-                    pf[t][ksub >> 1][(ksub & 1) * 4 + j] = (half_t)pv;
+                    p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ksub][t][j], scale_log2e, nm));
+                    if (!ONES) psum += p[j];
                 }
-            lrun[t] = lrun[t] * alpha + psum;
-#pragma unroll
-            for (int i = 0; i < DT; ++i) o[i][t] *= alpha;
+                pf[t][ksub >> 1][(ksub & 1) * 2] = pack_rtz(p[0], p[1]);
+                pf[t][ksub >> 1][(ksub & 1) * 2 + 1] = pack_rtz(p[2], p[3]);
+            }
+            if (!ONES) lrun[t] += psum;
         }
 
         // ---- O^T += V^T P^T ----
@@ -158,8 +237,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                 union { struct { s4v a, b; } p; h8 v; } u;
                 u.p.a = lo; u.p.b = hi;
 #pragma unroll
-                for (int t = 0; t < QT; ++t)
-                    o[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pf[t][kk], o[i][t], 0, 0, 0);
+                for (int t = 0; t < QT; ++t) {
+                    union { unsigned w[4]; h8 v; } pb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pb.w[e] = pf[t][kk][e];
+                    o[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pb.v, o[i][t], 0, 0, 0);
+                }
             }
         }
     }
@@ -168,9 +251,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     half_t* ob = out + (long)b * Tq * ldo + h * D;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        float l = lrun[t];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if (ONES) {
+            // row D of O^T = sum_k P: held by lane group (D % 16) / 4, register D % 4
+            constexpr int LT = D / 16, LQ = (D % 16) / 4, LJ = D % 4;
+            l = __shfl(o[LT][t][LJ], LQ * 16 + fr);
+        } else {
+            l = lrun[t];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int qi = q0 + t * 16 + fr;
 #pragma unroll

@@ -33,8 +33,20 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// Exact-erf GELU (diffusers GEGLU uses F.gelu's default, not the tanh form).  erf through
+// Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16 output rounding) with raw
+// v_rcp_f32 / v_exp_f32: ~14 VALU ops instead of libm erff's branchy polynomial.
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = __builtin_fmaf(-poly * t, e, 1.0f);       // erf(|x| / sqrt 2)
+    const float erf_signed = __builtin_copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_signed);
 }
 // XCD-aware, bijective block-id remap (8 XCDs, round-robin dispatch): blocks that end up on one
 // XCD get a contiguous range of tile ids so neighbouring tiles share that XCD's L2.

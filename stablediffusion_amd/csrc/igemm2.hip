@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     constexpr int LDC = BN + 8;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA rows must divide over the waves");
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be MFMA-shaped");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth (a 4-deep ring measured slower: one block per CU)");
 
     // The body is device-only: clang's host pass cannot type-check the gfx950 LDS-DMA builtin
     // (16-byte size) and would silently drop the kernel's host stub.
@@ -365,7 +365,7 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
-        if (p.geglu && (*variant == 2 || *variant == 5 || *variant == 3 || *variant == 4)) *variant = 1;
+        if (p.geglu && *variant != 0 && *variant != 1) *variant = 1;
         if (p.geglu) *splits = 1;
         return;
     }

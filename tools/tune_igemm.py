@@ -53,8 +53,8 @@ def main():
         row = {"shape": list(key), "tag": c.tag, "M": c.M, "N": c.Cout, "K": c.K, "count": e["count"],
                "gflop": c.flops / 1e9, "times_us": {}}
         nk = c.K // 64
-        for v in range(6):
-            if c.geglu and v in (2, 3, 4, 5):
+        for v in range(len(NAMES)):
+            if c.geglu and v not in (0, 1):
                 continue
             for sp in (1, 2, 3, 4, 6, 8):
                 if sp > 1 and (c.geglu or nk // sp < 8):
@@ -81,7 +81,7 @@ def main():
         bv, bs = best.split("/")
         print(f"M={c.M:7d} N={c.Cout:5d} K={c.K:6d} ks{c.ks} s{c.stride} u{c.up} g{c.geglu} x{e['count']:2d} "
               f"best {NAMES[int(bv)]:>10s}/k{bs} {bt:8.1f}us {c.flops / bt / 1e6:7.1f} TF | heur {row['heuristic_us']:8.1f}us | "
-              + " ".join(f"{NAMES[v][:7]}:{row['times_us'].get(f'{v}/1', float('nan')):.0f}" for v in range(6)), flush=True)
+              + " ".join(f"{NAMES[v][:7]}:{row['times_us'].get(f'{v}/1', float('nan')):.0f}" for v in range(len(NAMES))), flush=True)
         results.append(row)
     print(f"sum(best) = {total_best / 1e3:.3f} ms for {total_flops / 1e12:.3f} TFLOP -> {total_flops / total_best / 1e6:.1f} TF/s")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
