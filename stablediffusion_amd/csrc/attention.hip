@@ -73,13 +73,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 
     // ---- one-time LDS padding: K columns [D, DK) = 0 (the Q pad is zero too), V columns
     //      [D, VSTR) = 0 with a column of ones at D when the denominator rides on the PV MFMA ----
-    for (int idx = tid; idx < KT * (KSTR - D); idx += 256) {
-        const int r = idx / (KSTR - D), c = D + idx - r * (KSTR - D);
-        sK[r * KSTR + c] = (half_t)0.f;
+    constexpr int KPAD = KSTR - D, VPAD = VSTR - D;
+    if constexpr (KPAD > 0) {
+        for (int idx = tid; idx < KT * KPAD; idx += 256) {
+            const int r = idx / KPAD, c = D + idx - r * KPAD;
+            sK[r * KSTR + c] = (half_t)0.f;
+        }
     }
-    for (int idx = tid; idx < KT * (VSTR - D); idx += 256) {
-        const int r = idx / (VSTR - D), c = D + idx - r * (VSTR - D);
-        sV[r * VSTR + c] = (ONES && c == D) ? (half_t)1.f : (half_t)0.f;
+    if constexpr (VPAD > 0) {
+        for (int idx = tid; idx < KT * VPAD; idx += 256) {
+            const int r = idx / VPAD, c = D + idx - r * VPAD;
+            sV[r * VSTR + c] = (ONES && c == D) ? (half_t)1.f : (half_t)0.f;
+        }
     }
 
     // Q fragments (B operand of S^T = K Q^T): lane holds Q[query fr][32 ks + 8 fq .. +8]

@@ -20,8 +20,6 @@ namespace sd {
 namespace {
 
 constexpr int BK = 64;
-constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any buffer -> DMA writes zeros
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -30,6 +28,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmParams p, float* partial,
                                                                       int k_tiles_per_split) {
+    static_assert((BM / 8) % (WAVES_M * WAVES_N) == 0 && (BN / 8) % (WAVES_M * WAVES_N) == 0,
+                  "DMA rows must divide over the waves");
+    static_assert((BM / WAVES_M) % 16 == 0 && (BN / WAVES_N) % 16 == 0, "wave tile must be MFMA-shaped");
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth (a 4-deep ring measured slower: one block per CU)");
+
+    // The body is device-only: clang's host pass cannot type-check the gfx950 LDS-DMA builtin
+    // (16-byte size) and would silently drop the kernel's host stub.
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr unsigned kOOB = 0x80000000u;   // byte offset beyond any buffer -> DMA writes zeros
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int NT = 64 * NW;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -38,13 +45,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     constexpr int LPW = A_PW + B_PW;
     constexpr int STAGE_HALVES = (BM + BN) * BK;
     constexpr int LDC = BN + 8;
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA rows must divide over the waves");
-    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be MFMA-shaped");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth (a 4-deep ring measured slower: one block per CU)");
-
-    // The body is device-only: clang's host pass cannot type-check the gfx950 LDS-DMA builtin
-    // (16-byte size) and would silently drop the kernel's host stub.
-#if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* ring = reinterpret_cast<half_t*>(smem);
     half_t* sC = reinterpret_cast<half_t*>(smem);

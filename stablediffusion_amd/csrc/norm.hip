@@ -10,19 +10,32 @@
 namespace sd {
 namespace {
 
-constexpr int GN_CCB = 64;  // channel chunks (of 8) per block in the stats pass
+constexpr int GN_MAX_CB = 512;   // channels per stats block (upper bound)
 
-// Pass 1: per-(n, slab, channel) sum and sum of squares.  part[((n*S + s)*C + c)*2 + {0,1}]
+// Channels per stats block: a multiple of lcm(channels-per-group, 8) so that no group and no
+// 16-byte chunk straddles two blocks.
+__host__ __device__ inline int gn_block_channels(int C, int G) {
+    const int cpg = C / G;
+    int unit = cpg;
+    while (unit % 8 != 0) unit += cpg;          // lcm(cpg, 8)
+    int cb = unit;
+    while (cb + unit <= GN_MAX_CB && cb + unit <= C) cb += unit;
+    return cb > C ? C : cb;
+}
+
+// Pass 1: per-(n, slab, group) sum and sum of squares.  part[((n*S + s)*G + g)*2 + {0,1}]
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, long ldx,
                                                        float* __restrict__ part, long HW, int C,
-                                                       int S, int ccb) {
+                                                       int G, int S, int CB) {
     __shared__ float red[256 * 16];
+    __shared__ float chan[GN_MAX_CB * 2];
     const int n = blockIdx.z, s = blockIdx.y, cb = blockIdx.x;
-    const int CC = C >> 3;
     const int tid = threadIdx.x;
+    const int c0 = cb * CB;
+    const int cw = (C - c0 < CB) ? C - c0 : CB;      // channels in this block
+    const int ccb = cw >> 3;
     const int rows_par = 256 / ccb;
     const int cc_l = tid % ccb, prow = tid / ccb;
-    const int cc = cb * ccb + cc_l;
     const long rows_per = (HW + S - 1) / S;
     const long p0 = (long)s * rows_per;
     long p1 = p0 + rows_per;
@@ -30,10 +43,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     float sm[8], sq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
-    const bool active = prow < rows_par && cc < CC;
-    if (active) {
-        const half_t* base = x + ((long)n * HW) * ldx + cc * 8;
-        for (long pix = p0 + prow; pix < p1; pix += rows_par) {
+    if (prow < rows_par) {
+        const half_t* base = x + ((long)n * HW) * ldx + c0 + cc_l * 8;
+        long pix = p0 + prow;
+        // four independent 16-byte loads in flight per thread (HBM latency, not VALU, is the limit)
+        for (; pix + 3L * rows_par < p1; pix += 4L * rows_par) {
+            h8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h8*>(base + (pix + (long)u * rows_par) * ldx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; sm[e] += f; sq[e] += f * f; }
+        }
+        for (; pix < p1; pix += rows_par) {
             const h8 v = *reinterpret_cast<const h8*>(base + pix * ldx);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sm[e] += f; sq[e] += f * f; }
@@ -42,76 +65,93 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = sm[e]; red[tid * 16 + 8 + e] = sq[e]; }
     __syncthreads();
-    // fixed-order reduction over the pixel-parallel rows
-    if (prow == 0 && cc < CC) {
+    // fixed-order reduction over the pixel-parallel rows -> per-channel sums in LDS
+    if (prow == 0) {
         for (int r = 1; r < rows_par; ++r) {
             const int o = (r * ccb + cc_l) * 16;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sm[e] += red[o + e]; sq[e] += red[o + 8 + e]; }
         }
-        float* dst = part + (((long)n * S + s) * C + cc * 8) * 2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dst[e * 2] = sm[e]; dst[e * 2 + 1] = sq[e]; }
+        for (int e = 0; e < 8; ++e) { chan[(cc_l * 8 + e) * 2] = sm[e]; chan[(cc_l * 8 + e) * 2 + 1] = sq[e]; }
     }
-}
-
-// Pass 2: one wave per (n, group): reduce slabs x channels-of-group -> mean, rstd.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part,
-                                                         float* __restrict__ stats, long HW, int C,
-                                                         int G, int S, float eps) {
-    const int n = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    __syncthreads();
     const int cpg = C / G;
-    const int total = S * cpg;
-    float sm = 0.f, sq = 0.f;
-    for (int i = lane; i < total; i += 64) {
-        const int s = i / cpg, c = g * cpg + (i - s * cpg);
-        const float* src = part + (((long)n * S + s) * C + c) * 2;
-        sm += src[0]; sq += src[1];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sm += __shfl_xor(sm, off);
-        sq += __shfl_xor(sq, off);
-    }
-    if (lane == 0) {
-        const float cnt = (float)HW * (float)cpg;
-        const float mean = sm / cnt;
-        float var = sq / cnt - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        stats[((long)n * G + g) * 2] = mean;
-        stats[((long)n * G + g) * 2 + 1] = rsqrtf(var + eps);
+    const int ng = cw / cpg;
+    if (tid < ng) {
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < cpg; ++c) { a += chan[(tid * cpg + c) * 2]; b += chan[(tid * cpg + c) * 2 + 1]; }
+        float* dst = part + (((long)n * S + s) * G + c0 / cpg + tid) * 2;
+        dst[0] = a; dst[1] = b;
     }
 }
 
-// Pass 3: y = act((x - mean) * rstd * gamma + beta)
+// Pass 2: y = act((x - mean) * rstd * gamma + beta); the slab partials are reduced (fixed order)
+// in the prologue of every block -- no separate finalize launch.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, long ldx,
-                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ part,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        half_t* __restrict__ y, long ldy, long HW,
-                                                       int C, int G, int S, int silu) {
+                                                       int C, int G, int S, int SA, float eps, int silu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);  // [C] scale
     float* sh = sc + C;                          // [C] shift
+    float* st = sh + C;                          // [G][2] mean, rstd
     const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
+    if (tid < G) {
+        float a = 0.f, b = 0.f;
+        const float* src = part + ((long)n * S * G + tid) * 2;
+        for (int k = 0; k < S; ++k) { a += src[(long)k * G * 2]; b += src[(long)k * G * 2 + 1]; }
+        const float cnt = (float)HW * (float)cpg;
+        const float mean = a / cnt;
+        float var = b / cnt - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        st[tid * 2] = mean;
+        st[tid * 2 + 1] = rsqrtf(var + eps);
+    }
+    __syncthreads();
     for (int c = tid; c < C; c += 256) {
         const int g = c / cpg;
-        const float mean = stats[((long)n * G + g) * 2], rstd = stats[((long)n * G + g) * 2 + 1];
-        const float a = rstd * gamma[c];
+        const float a = st[g * 2 + 1] * gamma[c];
         sc[c] = a;
-        sh[c] = beta[c] - mean * a;
+        sh[c] = beta[c] - st[g * 2] * a;
     }
     __syncthreads();
     const int CC = C >> 3;
-    const long rows_per = (HW + S - 1) / S;
+    const long rows_per = (HW + SA - 1) / SA;
     const long p0 = (long)s * rows_per;
     long p1 = p0 + rows_per;
     if (p1 > HW) p1 = HW;
     const long total = (p1 - p0) * CC;
     const half_t* xb = x + ((long)n * HW + p0) * ldx;
     half_t* yb = y + ((long)n * HW + p0) * ldy;
-    for (long i = tid; i < total; i += 256) {
+    long i = tid;
+    for (; i + 3 * 256 < total; i += 4 * 256) {     // four loads in flight per thread
+        h8 v[4];
+        long pixs[4];
+        int cs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long ii = i + u * 256;
+            pixs[u] = ii / CC;
+            cs[u] = (int)(ii - pixs[u] * CC) * 8;
+            v[u] = *reinterpret_cast<const h8*>(xb + pixs[u] * ldx + cs[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[u][e] * sc[cs[u] + e] + sh[cs[u] + e];
+                if (silu) f = silu_f(f);
+                o[e] = (half_t)f;
+            }
+            *reinterpret_cast<h8*>(yb + pixs[u] * ldy + cs[u]) = o;
+        }
+    }
+    for (; i < total; i += 256) {
         const long pix = i / CC;
         const int c = (int)(i - pix * CC) * 8;
         const h8 v = *reinterpret_cast<const h8*>(xb + pix * ldx + c);
@@ -182,41 +222,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
-int gn_slabs(int N, long HW, int C) {
-    // aim for ~1024 blocks, at least 64 pixels per slab
-    const int cblocks = cdiv(C >> 3, GN_CCB);
+int gn_slabs(int N, long HW, int C, int G) {
+    // aim for ~1024 stats blocks, at least 64 pixels per slab, at most 256 slabs
+    const int cblocks = cdiv(C, gn_block_channels(C, G));
     long s = 1024 / ((long)N * cblocks);
     if (s < 1) s = 1;
     const long smax = HW / 64 > 0 ? HW / 64 : 1;
     if (s > smax) s = smax;
+    if (s > 256) s = 256;
     return (int)s;
 }
 
 }  // namespace
 
 long gn_scratch_floats(int N, long HW, int C, int G) {
-    const int S = gn_slabs(N, HW, C);
-    return (long)N * S * C * 2 + (long)N * G * 2;
+    return (long)N * gn_slabs(N, HW, C, G) * G * 2;
 }
 
 int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y,
                      long ldy, int N, long HW, int C, int G, float eps, int silu, float* scratch,
                      hipStream_t s) {
-    if (C % 8 != 0 || C % G != 0) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
-    const int S = gn_slabs(N, HW, C);
-    const int CC = C >> 3;
-    const int ccb = CC < GN_CCB ? CC : GN_CCB;
-    float* part = scratch;
-    float* stats = scratch + (long)N * S * C * 2;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(CC, ccb), S, N), dim3(256), 0, s, x, ldx, part, HW, C, S, ccb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(64), 0, s, part, stats, HW, C, G, S, eps);
-    // apply pass: finer slabs for parallelism
+    if (C % 8 != 0 || C % G != 0 || G > 256) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
+    const int S = gn_slabs(N, HW, C, G);
+    const int CB = gn_block_channels(C, G);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
     int SA = (int)(2048 / N);
     if (SA < 1) SA = 1;
     const long samax = HW / 16 > 0 ? HW / 16 : 1;
     if (SA > samax) SA = (int)samax;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(SA, N), dim3(256), (size_t)C * 2 * sizeof(float), s, x, ldx,
-                       stats, gamma, beta, y, ldy, HW, C, G, SA, silu);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(SA, N), dim3(256), ((size_t)C * 2 + (size_t)G * 2) * sizeof(float), s,
+                       x, ldx, scratch, gamma, beta, y, ldy, HW, C, G, S, SA, eps, silu);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -329,7 +329,7 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
 void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu) {
     float* scratch = c.arena->alloc_f(gn_scratch_floats(N, HW, n.C, G));
     if (c.dry || c.err) return;
-    prof_open(c.stream, "groupnorm(3 kernels)", 0.0, 4.0 * N * HW * n.C);
+    prof_open(c.stream, "groupnorm(stats+apply)", 0.0, 4.0 * N * HW * n.C);
     c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream);
     prof_close(c.stream);
 }
