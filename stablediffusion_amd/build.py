@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsd_engine.so")
 SOURCES = ["igemm.hip", "igemm2.hip", "norm.hip", "attention.hip", "misc.hip", "runtime.cpp", "unet.cpp", "vae.cpp", "capi.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast"]
+         "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _stale(target, deps):

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const h8*>(wrow[i] + k0);
-        ci0 += BK;
-        if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
+        // K order = [Cin/64][KH][KW][64] (misc.hip pack_conv_kernel): taps innermost
+        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ci0 += BK; } }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll

@@ -25,11 +25,10 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW, bool STAG>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmParams p, float* partial,
                                                                       int k_tiles_per_split) {
-    static_assert((BM / 8) % (WAVES_M * WAVES_N) == 0 && (BN / 8) % (WAVES_M * WAVES_N) == 0,
-                  "DMA rows must divide over the waves");
+    static_assert((BM / 8) % (WAVES_M * WAVES_N) == 0, "A-tile DMA rows must divide over the waves");
     static_assert((BM / WAVES_M) % 16 == 0 && (BN / WAVES_N) % 16 == 0, "wave tile must be MFMA-shaped");
     static_assert(STAGES == 2 || STAGES == 3, "ring depth (a 4-deep ring measured slower: one block per CU)");
 
@@ -41,8 +40,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     constexpr int NT = 64 * NW;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_PW = BM / 8 / NW, B_PW = BN / 8 / NW;     // DMA instructions per wave per slab
-    constexpr int LPW = A_PW + B_PW;
+    // DMA instructions per wave per slab.  The B tile may not divide evenly over the waves
+    // (160 rows / 8 waves): the first B_REM waves then issue one instruction more.
+    constexpr int A_PW = BM / 8 / NW;
+    constexpr int B_INSTR = BN / 8, B_REM = B_INSTR % NW, B_PW = (B_INSTR + NW - 1) / NW;
+    constexpr int LPW = A_PW + B_PW;            // waves < B_REM (or all, when even)
+    constexpr int LPW_LO = A_PW + B_PW - 1;     // waves >= B_REM when uneven
     constexpr int STAGE_HALVES = (BM + BN) * BK;
     constexpr int LDC = BN + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,16 +99,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
             a_base[j] = (unsigned)(((long)n * p.H * p.W * p.ldx + chunk * 8) * 2);
         }
     }
+    const bool b_hi = (B_REM == 0) || wave < B_REM;               // wave-uniform
+    const int b_cnt = b_hi ? B_PW : B_PW - 1;
+    const int b_first = b_hi ? wave * B_PW : B_REM * B_PW + (wave - B_REM) * (B_PW - 1);
     unsigned b_off[B_PW];
 #pragma unroll
     for (int j = 0; j < B_PW; ++j)
-        b_off[j] = (unsigned)((((long)(n0 + (wave * B_PW + j) * 8 + lrow)) * p.K + chunk * 8) * 2);
+        b_off[j] = (unsigned)((((long)(n0 + (b_first + j) * 8 + lrow)) * p.K + chunk * 8) * 2);
 
     // tap state of the NEXT slab to issue
+    // K order = [Cin/64][KH][KW][64] (misc.hip pack_conv_kernel): taps innermost
     int k0 = kt_begin * BK;
-    int tap = k0 / p.Cin;
-    int ci0 = k0 - tap * p.Cin;
-    int kh = tap / p.KS, kw = tap - kh * p.KS;
+    const int taps = p.KS * p.KS;
+    int ci0 = (kt_begin / taps) * BK;
+    const int tap0 = kt_begin % taps;
+    int kh = tap0 / p.KS, kw = tap0 - kh * p.KS;
     const unsigned row_bytes = (unsigned)(p.ldx * 2);
 
     auto issue = [&](int slot) {
@@ -128,12 +136,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
         }
 #pragma unroll
         for (int j = 0; j < B_PW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rw, (__attribute__((address_space(3))) void*)(sb + (wave * B_PW + j) * 512), 16,
-                b_off[j] + (unsigned)(k0 * 2), 0, 0, 0);
+            if (j < b_cnt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rw, (__attribute__((address_space(3))) void*)(sb + (b_first + j) * 512), 16,
+                    b_off[j] + (unsigned)(k0 * 2), 0, 0, 0);
         k0 += BK;
-        ci0 += BK;
-        if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
+        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ci0 += BK; } }
     };
 
     f4 acc[TM][TN];
@@ -151,9 +159,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt must have landed; at most D-1 younger stages may stay in flight
-        if (D == 2 && kt + 1 < nk) wait_vmcnt<LPW>(); else wait_vmcnt<0>();
+        if (D == 2 && kt + 1 < nk) {
+            if (b_hi) wait_vmcnt<LPW>(); else wait_vmcnt<LPW_LO>();
+        } else {
+            wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
-        if (kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);   // (kt + D) % STAGES == (kt - 1) % STAGES
+        // (kt + D) % STAGES == (kt - 1) % STAGES.  With STAG the second wave group (the SIMD partners
+        // of waves 0-3) issues its DMA after its MFMAs instead of before them, so on every SIMD one
+        // wave is in its address/DMA-issue phase while the other feeds the matrix pipe.
+        const bool late = STAG && wave >= NW / 2;
+        if (!late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
         const half_t* cA = ring + slot * STAGE_HALVES;
         const half_t* cB = cA + BM * BK;
 #pragma unroll
@@ -176,6 +192,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+        if (late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
         slot = (slot + 1 == STAGES) ? 0 : slot + 1;
     }
 
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool PW>
+template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG>
 int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(half_t);
@@ -298,7 +315,7 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, STAGES, PW>),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -306,7 +323,7 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     const int nk = p.K / BK;
     const int per = cdiv(nk, splits);
     const int eff_splits = cdiv(nk, per);
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
                        p, eff_splits > 1 ? partial : nullptr, per);
     SD_HIP_CHECK(hipGetLastError());
     if (eff_splits > 1) {
@@ -319,10 +336,11 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool STAG = false>
 int launch_v2(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
-    if (p.KS == 1 && p.stride == 1 && p.up == 0) return launch_v2p<BM, BN, WM, WN, STAGES, true>(p, partial, splits, s);
-    return launch_v2p<BM, BN, WM, WN, STAGES, false>(p, partial, splits, s);
+    if (p.KS == 1 && p.stride == 1 && p.up == 0)
+        return launch_v2p<BM, BN, WM, WN, STAGES, true, STAG>(p, partial, splits, s);
+    return launch_v2p<BM, BN, WM, WN, STAGES, false, STAG>(p, partial, splits, s);
 }
 
 int g_force_variant = -1;
@@ -334,8 +352,9 @@ int g_force_splits = 0;
 //   0: 256x128 8 waves 3 stages   1: 128x128 4 waves 2 stages   2: 128x160 4 waves 2 stages
 //   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
 static const char* kIgemm2Names[] = {"igemm2<256,128,s3>", "igemm2<128,128,s2>", "igemm2<128,160,s2>",
-                                     "igemm2<128,64,s2>",  "igemm2<64,64,s2>",   "igemm2<256,160,s3>"};
-constexpr int kNumVariants = 6;
+                                     "igemm2<128,64,s2>",  "igemm2<64,64,s2>",   "igemm2<256,160,s3>",
+                                     "igemm2<256,128,s3,stag>", "igemm2<256,160,8w,s3,stag>"};
+constexpr int kNumVariants = 8;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -347,7 +366,7 @@ bool igemm2_supported(const IGemmParams& p) {
 }
 
 static void tile_dims(int v, int* bm, int* bn) {
-    static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}};
+    static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -365,7 +384,7 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
-        if (p.geglu && *variant != 0 && *variant != 1) *variant = 1;
+        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6) *variant = 1;
         if (p.geglu) *splits = 1;
         return;
     }
@@ -417,6 +436,8 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 3: return launch_v2<128, 64, 2, 2, 2>(p, partial, sp, s);
         case 4: return launch_v2<64, 64, 2, 2, 2>(p, partial, sp, s);
         case 5: return launch_v2<256, 160, 4, 1, 3>(p, partial, sp, s);
+        case 6: return launch_v2<256, 128, 4, 2, 3, true>(p, partial, sp, s);
+        case 7: return launch_v2<256, 160, 4, 2, 3, true>(p, partial, sp, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

@@ -136,6 +136,10 @@ __global__ void pointwise_nchw_kernel(const half_t* __restrict__ x, const half_t
     y[i] = (half_t)acc;
 }
 
+// K order of a packed KxK conv weight row (Cin % 64 == 0): [Cin/64][KH][KW][64] -- the nine taps of
+// one 64-channel slab are consecutive, so the implicit-GEMM gather re-reads the same input lines
+// nine times back to back (L2 hits) instead of streaming the whole tile footprint once per tap.
+// Small-Cin convs (conv_in, via im2col) keep [KH][KW][Cin].
 __global__ void pack_conv_kernel(const half_t* __restrict__ w, half_t* __restrict__ wp, int O, int I,
                                  int KH, int KW, long Kpad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over O * Kpad
@@ -144,8 +148,16 @@ __global__ void pack_conv_kernel(const half_t* __restrict__ w, half_t* __restric
     const long o = i / Kpad;
     half_t val = (half_t)0.f;
     if (kq < (long)KH * KW * I) {
-        const int ci = (int)(kq % I);
-        const int tap = (int)(kq / I);
+        int ci, tap;
+        if (I % 64 == 0) {
+            const int slab = (int)(kq >> 6), cl = (int)(kq & 63);
+            const int cs = slab / (KH * KW);
+            tap = slab - cs * (KH * KW);
+            ci = cs * 64 + cl;
+        } else {
+            ci = (int)(kq % I);
+            tap = (int)(kq / I);
+        }
         const int kh = tap / KW, kw = tap - kh * KW;
         val = w[((o * I + ci) * KH + kh) * KW + kw];
     }

@@ -205,3 +205,44 @@ def test_cfg_ddim_step_kernels(engine_lib):
     assert engine_lib.sd_cfg_ddim_step(C.c_void_p(eps.data_ptr()), C.c_void_p(out.data_ptr()), lat.numel(), 5.0, cx, ce, st) == 0
     torch.cuda.synchronize()
     assert rel_l2(out, ref) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size SD1.5 (BASELINE.json config C1: 256x256, 10-step DDIM, batch 1, CFG on)
+# ---------------------------------------------------------------------------------------------
+def test_sd15_full_size_c1_against_oracle(engine_lib):
+    """The real SD1.5 topology and widths (859.5 M-parameter UNet, 83.7 M VAE) with seeded synthetic
+    weights: one UNet forward, the 10-step DDIM latents and the decoded image against the fp32 CPU
+    oracle on identical fp16-rounded weights / inputs.  Tolerance: rel-L2 <= 1e-2 (BASELINE.json)."""
+    import os
+
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ucfg, vcfg = config.sd15_unet(), config.sd15_vae()
+    usd = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=21, dtype=torch.float16)
+    vsd = weights.synth_state_dict(weights.vae_manifest(vcfg), seed=22, dtype=torch.float16)
+    unet = HipUNet2DConditionModel(ucfg).load_state_dict(usd)
+    vae = HipAutoencoderKL(vcfg).load_state_dict(vsd)
+    uw = {k: v.float() for k, v in usd.items()}
+    vw = {k: v.float() for k, v in vsd.items()}
+    g = torch.Generator().manual_seed(77)
+    lat0 = torch.randn(1, 4, 32, 32, generator=g).half()
+    emb2 = torch.randn(2, 77, 768, generator=g).half()          # [negative ; positive]
+    # (1) single forward at CFG batch 2
+    x2 = torch.cat([lat0, lat0])
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(ucfg, uw, x2.float(), torch.tensor(901.0), emb2.float())
+    got = unet(x2.cuda(), torch.tensor(901.0), emb2.cuda())[0]
+    assert rel_l2(got, ref) < TOL
+    # (2) 10-step DDIM + decode through the pipeline surface
+    model = SDModelWrapper(base=unet, vae=vae, scheduler=DDIMScheduler(), device="cuda")
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda")
+    images = pipe(model, prompt_embeds=emb2[1:], negative_prompt_embeds=emb2[:1], latents=lat0,
+                  num_inference_steps=10, guidance_scale=5.0, height=256, width=256)
+    with torch.no_grad():
+        ref_img, ref_lat = pipeline_ref.txt2img_ref(ucfg, uw, vcfg, vw, lat0.float(), emb2.float(), steps=10,
+                                                    guidance_scale=5.0)
+    assert images.shape == (1, 3, 256, 256)
+    assert torch.isfinite(images.float()).all()
+    assert rel_l2(images, ref_img) < TOL

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from stablediffusion_amd import _lib, config, shapes  # noqa: E402
 
-NAMES = ["256x128s3", "128x128s2", "128x160s2", "128x64s2", "64x64s2", "256x160s3"]
+NAMES = ["256x128s3", "128x128s2", "128x160s2", "128x64s2", "64x64s2", "256x160s3", "256x128stag", "256x160w8"]
 
 
 def main():
@@ -54,7 +54,7 @@ def main():
                "gflop": c.flops / 1e9, "times_us": {}}
         nk = c.K // 64
         for v in range(len(NAMES)):
-            if c.geglu and v not in (0, 1):
+            if c.geglu and v not in (0, 1, 6):
                 continue
             for sp in (1, 2, 3, 4, 6, 8):
                 if sp > 1 and (c.geglu or nk // sp < 8):
