@@ -36,7 +36,7 @@ from stablediffusion_amd.schedulers import DDIMScheduler  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md:43
 HBM_PEAK_GBS = 8000.0       # spec; 6.29 TB/s achievable (MI355X_MICROARCH.md:36)
 # algorithmic TFLOP per unit (2*MAC of conv / linear / QK^T / PV only)
-UNET_TFLOP_PER_SAMPLE = {32: 0.1803, 64: 0.8032, 96: 2.148, 128: 4.674}
+UNET_TFLOP_PER_SAMPLE = {"sd15": {32: 0.1803, 64: 0.8032, 96: 2.148, 128: 4.674}, "sdxl": {128: 6.761}}
 VAE_TFLOP_PER_IMAGE = {32: 0.622, 64: 2.515, 96: 5.754, 128: 10.470}
 
 
@@ -56,15 +56,15 @@ def build_models(device, preset="sd15", seed=2):
     return ucfg, vcfg, usd, vsd, unet, vae
 
 
-def live_roofline(lib, unet, vae, B, lat_hw, ehs, device):
+def live_roofline(lib, unet, vae, B, lat_hw, ehs, device, added=None):
     """One profiled UNet forward (CFG batch 2B) + one decode: per-kernel HIP-event times."""
     x = torch.randn(2 * B, 4, lat_hw, lat_hw, device=device, dtype=torch.float16)
     z = torch.randn(B, 4, lat_hw, lat_hw, device=device, dtype=torch.float16)
     t = torch.tensor(501.0)
-    unet(x, t, ehs)           # warm
+    unet(x, t, ehs, added_cond_kwargs=added)           # warm
     torch.cuda.synchronize()
     lib.sd_prof_enable(1)
-    unet(x, t, ehs)
+    unet(x, t, ehs, added_cond_kwargs=added)
     ents = (_lib.SdProfEntry * 64)()
     n = C.c_int()
     _lib.check(lib.sd_prof_collect(ents, 64, C.byref(n)), "sd_prof_collect")
@@ -98,7 +98,8 @@ def cpu_baseline(ucfg, vcfg, usd, vsd, steps, lat_hw, ehs_len):
     cores = usable_cores()
     torch.set_num_threads(cores)
     hw = lat_hw // 2
-    u_scale = UNET_TFLOP_PER_SAMPLE.get(lat_hw, 4 * UNET_TFLOP_PER_SAMPLE.get(hw, 1)) / UNET_TFLOP_PER_SAMPLE.get(hw, 1)
+    ut = UNET_TFLOP_PER_SAMPLE["sd15"]
+    u_scale = ut.get(lat_hw, 4 * ut.get(hw, 1)) / ut.get(hw, 1)
     v_scale = VAE_TFLOP_PER_IMAGE.get(lat_hw, 4 * VAE_TFLOP_PER_IMAGE.get(hw, 1)) / VAE_TFLOP_PER_IMAGE.get(hw, 1)
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
@@ -132,6 +133,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="latents per GPU")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--guidance", type=float, default=5.0)
+    ap.add_argument("--preset", default="sd15", choices=["sd15", "sdxl"],
+                    help="sd15 = BASELINE.json metric (C2); sdxl with --res 1024 --batch 2 --denoise-steps 30 "
+                         "--scheduler 'DPM++ 2M' = config C4")
+    ap.add_argument("--scheduler", default="DDIM", choices=["DDIM", "DPM++ 2M", "euler"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -146,8 +151,10 @@ def main():
     device = torch.device("cuda", local_rank)
     lib = _lib.load()
 
-    ucfg, vcfg, usd, vsd, unet, vae = build_models(device)
-    model = SDModelWrapper(base=unet, vae=vae, scheduler=DDIMScheduler(), device=str(device))
+    ucfg, vcfg, usd, vsd, unet, vae = build_models(device, args.preset)
+    model = SDModelWrapper(base=unet, vae=vae, scheduler=DDIMScheduler(), device=str(device),
+                           model_type=args.preset)
+    model.set_scheduler(args.scheduler)
     pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device=str(device))
 
     B = args.batch
@@ -158,11 +165,18 @@ def main():
     ge = torch.Generator().manual_seed(1)
     pe_full = torch.randn(total, 77, ucfg.cross_attention_dim, generator=ge).half().to(device)
     ne_full = torch.randn(total, 77, ucfg.cross_attention_dim, generator=ge).half().to(device)
+    pooled = npooled = None
+    if args.preset == "sdxl":
+        pdim = ucfg.projection_class_embeddings_input_dim - 6 * ucfg.addition_time_embed_dim
+        pooled = torch.randn(total, pdim, generator=ge).half().to(device)
+        npooled = torch.randn(total, pdim, generator=ge).half().to(device)
     if rank != 0:   # non-root ranks receive the embeddings through the broadcast
         pe_full.zero_(); ne_full.zero_()
+        if pooled is not None:
+            pooled.zero_(); npooled.zero_()
 
     def one_pass():
-        return sdd.sharded_txt2img(pipe, model, lat_full, pe_full, ne_full, rank, n_gpus,
+        return sdd.sharded_txt2img(pipe, model, lat_full, pe_full, ne_full, rank, n_gpus, pooled, npooled,
                                    num_inference_steps=args.denoise_steps, guidance_scale=args.guidance,
                                    height=args.res, width=args.res)
 
@@ -185,11 +199,15 @@ def main():
     e8 = torch.cat([ne_full[:B], pe_full[:B]])
     tt = torch.tensor(501.0)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    unet(x8, tt, e8); vae.decode(x8[:B])
+    added = None
+    if args.preset == "sdxl":
+        added = {"text_embeds": torch.cat([npooled[:B], pooled[:B]]),
+                 "time_ids": torch.tensor([[args.res, args.res, 0, 0, args.res, args.res]] * (2 * B), dtype=torch.float32)}
+    unet(x8, tt, e8, added_cond_kwargs=added); vae.decode(x8[:B])
     torch.cuda.synchronize()
     ev[0].record()
     for _ in range(10):
-        unet(x8, tt, e8)
+        unet(x8, tt, e8, added_cond_kwargs=added)
     ev[1].record(); ev[2].record()
     for _ in range(3):
         vae.decode(x8[:B])
@@ -199,14 +217,16 @@ def main():
 
     result = None
     if rank == 0:
-        u_tf = UNET_TFLOP_PER_SAMPLE.get(lat_hw)
+        u_tf = UNET_TFLOP_PER_SAMPLE[args.preset].get(lat_hw)
         v_tf = VAE_TFLOP_PER_IMAGE.get(lat_hw)
         result = {
-            "metric": "denoise-loop latents/s (512px, 50-step DDIM, batch 4)",
+            "metric": ("denoise-loop latents/s (512px, 50-step DDIM, batch 4)" if args.preset == "sd15" else
+                       f"denoise-loop latents/s ({args.res}px, {args.denoise_steps}-step {args.scheduler}, batch {B})"),
             "value": round(value, 4), "unit": "latents/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"SD1.5 {args.res}x{args.res}, {args.denoise_steps}-step DDIM, "
+            "config": {"workload": f"{'SD1.5' if args.preset == 'sd15' else 'SDXL-base'} {args.res}x{args.res}, "
+                                   f"{args.denoise_steps}-step {args.scheduler}, "
                                    f"batch {B}/GPU, CFG on (UNet batch {2 * B}), UNet + VAE decode HIP kernels",
                        "global_batch": total, "parallelism": f"dp{n_gpus}", "guidance_scale": args.guidance},
             "unet_forward_ms": round(unet_ms, 3), "vae_decode_ms": round(vae_ms, 3),
@@ -217,7 +237,7 @@ def main():
             result["whole_path_mfma_frac"] = round(tflop / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4)
             result["unet_forward_mfma_frac"] = round(2 * B * u_tf / (unet_ms / 1e3) / MFMA_PEAK_TFLOPS, 4)
         if not args.no_roofline:
-            urows, vrows = live_roofline(lib, unet, vae, B, lat_hw, e8, device)
+            urows, vrows = live_roofline(lib, unet, vae, B, lat_hw, e8, device, added)
             urows.sort(key=lambda r: -r[3])
             name, flops, nbytes, ms, launches = urows[0]
             if flops > 0:
@@ -246,7 +266,7 @@ def main():
                  "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,
                  "gbs": round(b / (m / 1e3) / 1e9, 1) if m > 0 else None}
                 for k, f, b, m, l in vrows]
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and args.preset == "sd15":
             del unet, vae, model
             torch.cuda.empty_cache()
             result["cpu_baseline"] = cpu_baseline(ucfg, vcfg, usd, vsd, args.denoise_steps, lat_hw, 77)

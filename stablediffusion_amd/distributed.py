@@ -87,16 +87,22 @@ def max_over_ranks(x: float, device) -> float:
 
 
 def sharded_txt2img(pipeline, model, latents_full: torch.Tensor, prompt_embeds_full: torch.Tensor,
-                    negative_embeds_full: torch.Tensor, rank: int, world: int, **call_kwargs) -> torch.Tensor:
+                    negative_embeds_full: torch.Tensor, rank: int, world: int,
+                    pooled_full: Optional[torch.Tensor] = None, negative_pooled_full: Optional[torch.Tensor] = None,
+                    **call_kwargs) -> torch.Tensor:
     """Run the pipeline on this rank's slice of the batch and return the full gathered batch.
 
     `latents_full` is generated once for the whole batch from the single seeded generator
     (`sd_unified_pipeline.py:773-781` semantics) so sharded == unsharded per sample.
     """
     total = latents_full.shape[0]
-    broadcast_tensors([prompt_embeds_full, negative_embeds_full])
+    extra = [t for t in (pooled_full, negative_pooled_full) if t is not None]
+    broadcast_tensors([prompt_embeds_full, negative_embeds_full] + extra)
     lat = shard(latents_full, rank, world)
     pe = shard(prompt_embeds_full, rank, world)
     ne = shard(negative_embeds_full, rank, world)
+    if pooled_full is not None:      # SDXL pooled text embeddings ride along with the same split
+        call_kwargs = dict(call_kwargs, pooled_prompt_embeds=shard(pooled_full, rank, world),
+                           negative_pooled_prompt_embeds=shard(negative_pooled_full, rank, world))
     images = pipeline(model, prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat, **call_kwargs)
     return all_gather_batch(images, total)

@@ -246,3 +246,25 @@ def test_sd15_full_size_c1_against_oracle(engine_lib):
     assert images.shape == (1, 3, 256, 256)
     assert torch.isfinite(images.float()).all()
     assert rel_l2(images, ref_img) < TOL
+
+
+def test_sdxl_full_size_unet_forward(engine_lib):
+    """SDXL-base UNet (2.57 B parameters: linear projections, depth-2/10 transformer stacks, head dim 64,
+    text_time conditioning) at a reduced spatial size against the fp32 CPU oracle."""
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ucfg = config.sdxl_unet()
+    usd = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=31, dtype=torch.float16)
+    unet = HipUNet2DConditionModel(ucfg).load_state_dict(usd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 32, 32, generator=g).half()
+    ehs = torch.randn(2, 77, 2048, generator=g).half()
+    added = {"text_embeds": torch.randn(2, 1280, generator=g).half(),
+             "time_ids": torch.tensor([[256.0, 256, 0, 0, 256, 256]] * 2)}
+    got = unet(x.cuda(), torch.tensor(621.0), ehs.cuda(), added_cond_kwargs=added)[0]
+    uw = {k: v.float() for k, v in usd.items()}
+    del usd
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(ucfg, uw, x.float(), torch.tensor(621.0), ehs.float(),
+                                    {"text_embeds": added["text_embeds"].float(), "time_ids": added["time_ids"]})
+    assert rel_l2(got, ref) < TOL
