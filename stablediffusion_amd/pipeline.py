@@ -14,7 +14,10 @@ Differences from the reference, on purpose:
     reference raises when `prompt is None` (`:565`).
   * reference defects listed in SURVEY.md §8b (relative import, tqdm.notebook, unbound `generator`,
     …) are not reproduced.  Quirk kept: the `output_type` kwarg is ignored, the constructor's wins.
-  * inpainting (`:268-380`, `:492-506`) is not implemented yet (SURVEY.md §8f is "next").
+  * inpainting (`:268-380`, `:492-506`): tensors only (image in [-1,1], mask in [0,1]; no PIL
+    resize / `padding_mask_crop`).  4-channel UNets blend with the re-noised original latents as the
+    reference does; 9-channel inpaint UNets get `[latents | mask | masked-image latents]`
+    concatenated before the UNet, which the reference omits (`:465-482`, listed as a defect).
 """
 from __future__ import annotations
 
@@ -118,9 +121,15 @@ class StableDiffusionUnifiedPipeline:
         if model.device != self.device:
             model.to(self.device)
         self.model = model
-        if mask_image is not None:
-            raise NotImplementedError("inpainting is not part of the engine yet (SURVEY.md §8f)")
+        if padding_mask_crop is not None:
+            raise NotImplementedError("padding_mask_crop needs the PIL image processor; pass pre-cropped tensors")
 
+        if isinstance(image, torch.Tensor) and image.shape[1] != 4:
+            # no PIL resize here: a pixel-space tensor fixes the working resolution
+            # (the reference resizes the image to height x width instead, :238 / :277-279)
+            if (height and height != image.shape[-2]) or (width and width != image.shape[-1]):
+                raise ValueError("height / width must match the image tensor (tensors are not resized)")
+            height, width = image.shape[-2], image.shape[-1]
         height = height or model.base.config.sample_size * model.vae_scale_factor
         width = width or model.base.config.sample_size * model.vae_scale_factor
 
@@ -146,10 +155,55 @@ class StableDiffusionUnifiedPipeline:
 
         timesteps, num_inference_steps = retrieve_timesteps(model.scheduler, num_inference_steps, self.device)
 
+        self.is_inpaint = False
+        mask = masked_image_latents_2b = image_latents = noise = None
+        num_channels_unet = model.base.config.in_channels
         if image is None:
             shape = (batch_size * num_images_per_prompt, model.base.config.in_channels,
                      height // model.vae_scale_factor, width // model.vae_scale_factor)
             latents = self.prepare_latents_txt2img(shape, prompt_embeds.dtype, seed, latents)
+        elif mask_image is not None:
+            # ---- inpaint (:268-380) ----
+            if not isinstance(image, torch.Tensor) or not isinstance(mask_image, torch.Tensor):
+                raise ValueError("inpainting takes torch tensors: image [B,3|4,H,W] in [-1,1], mask [B,1,H,W] in [0,1]")
+            init_image = image.to(torch.float32)
+            mask = (mask_image.to(torch.float32) >= 0.5).to(torch.float32)       # mask_processor: do_binarize
+            if mask.ndim == 3:
+                mask = mask[:, None]
+            if masked_image_latents is not None:
+                masked_image = masked_image_latents
+            elif init_image.shape[1] == 4:
+                masked_image = None
+            else:
+                masked_image = init_image * (mask < 0.5)
+            timesteps, num_inference_steps = self.get_timesteps(
+                num_inference_steps, strength, denoising_start if denoising_value_valid(denoising_start) else None)
+            if num_inference_steps < 1:
+                raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the "
+                                 f"number of pipeline steps is {num_inference_steps} which is < 1.")
+            latent_timestep = timesteps[:1].repeat(batch_size * num_images_per_prompt)
+            is_strength_max = strength == 1.0
+            num_channels_latents = model.vae.config.latent_channels
+            return_image_latents = num_channels_unet == 4
+            shape = (batch_size * num_images_per_prompt, num_channels_latents,
+                     height // model.vae_scale_factor, width // model.vae_scale_factor)
+            latents, noise, image_latents = self.prepare_latents_inpaint(
+                shape, prompt_embeds.dtype, seed, latents, init_image, latent_timestep, is_strength_max,
+                add_noise=denoising_start is None, return_image_latents=return_image_latents)
+            mask, masked_image_latents_2b = self.prepare_mask_latents(
+                mask, masked_image, batch_size * num_images_per_prompt, height // model.vae_scale_factor,
+                width // model.vae_scale_factor, prompt_embeds.dtype, seed)
+            if num_channels_unet == 9:
+                if masked_image_latents_2b is None:
+                    raise ValueError("a 9-channel inpaint UNet needs a pixel-space image (or masked_image_latents)")
+                if num_channels_latents + mask.shape[1] + masked_image_latents_2b.shape[1] != num_channels_unet:
+                    raise ValueError("Incorrect configuration settings! latents + mask + masked image channels "
+                                     f"!= unet in_channels ({num_channels_unet})")
+            elif num_channels_unet != 4:
+                raise ValueError(f"The unet {model.base.__class__} should have either 4 or 9 input channels, "
+                                 f"not {num_channels_unet}.")
+            height, width = (d * model.vae_scale_factor for d in latents.shape[-2:])
+            self.is_inpaint = True
         else:
             timesteps, num_inference_steps = self.get_timesteps(num_inference_steps, strength, denoising_start)
             latent_timestep = timesteps[:1].repeat(batch_size * num_images_per_prompt)
@@ -188,6 +242,9 @@ class StableDiffusionUnifiedPipeline:
         for i, t in enumerate(timesteps):
             latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
             latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
+            if self.is_inpaint and num_channels_unet == 9:
+                latent_model_input = torch.cat([latent_model_input, mask.to(latent_model_input.dtype),
+                                                masked_image_latents_2b.to(latent_model_input.dtype)], dim=1)
             noise_pred = model.base(latent_model_input, t, prompt_embeds,
                                     cross_attention_kwargs=cross_attention_kwargs,
                                     added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
@@ -195,6 +252,13 @@ class StableDiffusionUnifiedPipeline:
                 noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
                 noise_pred = guidance_scale * (noise_pred_text - noise_pred_uncond) + noise_pred_uncond
             latents = model.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            if self.is_inpaint and num_channels_unet == 4:          # :492-506
+                init_latents_proper = image_latents
+                init_mask = mask.chunk(2)[0] if self.do_classifier_free_guidance else mask
+                if i < len(timesteps) - 1:
+                    init_latents_proper = model.scheduler.add_noise(init_latents_proper, noise,
+                                                                    torch.as_tensor([timesteps[i + 1]]))
+                latents = ((1 - init_mask) * init_latents_proper.float() + init_mask * latents.float()).to(latents.dtype)
 
         # ---- decode (:511-529) ----
         if self.output_type == "pt":
@@ -319,6 +383,59 @@ class StableDiffusionUnifiedPipeline:
             noise = torch.randn(init_latents.shape, generator=generator, device=self.device, dtype=dtype)
             init_latents = self.model.scheduler.add_noise(init_latents, noise, timestep)
         return init_latents
+
+    def prepare_latents_inpaint(self, shape, dtype, seed=None, latents=None, image=None, timestep=None,
+                                is_strength_max=True, add_noise=True, return_image_latents=False):
+        """sd_unified_pipeline.py:848-913; always returns (latents, noise, image_latents-or-None)."""
+        batch_size = shape[0]
+        generator = None
+        if seed is not None:
+            generator = torch.Generator(device=self.device).manual_seed(int(seed))
+        if (image is None or timestep is None) and not is_strength_max:
+            raise ValueError("Since strength < 1. initial latents are to be initialised as a combination of Image + "
+                             "Noise. However, either the image or the noise timestep has not been provided.")
+        image_latents = None
+        if image.shape[1] == 4:
+            image_latents = image.to(device=self.device, dtype=dtype)
+            image_latents = image_latents.repeat(batch_size // image_latents.shape[0], 1, 1, 1)
+        elif return_image_latents or (latents is None and not is_strength_max):
+            image_latents = self._encode_vae_image(image.to(device=self.device, dtype=dtype), generator)
+            image_latents = image_latents.repeat(batch_size // image_latents.shape[0], 1, 1, 1)
+        if latents is None and add_noise:
+            noise = torch.randn(shape, generator=generator, device=self.device, dtype=dtype)
+            latents = noise if is_strength_max else self.model.scheduler.add_noise(image_latents, noise, timestep)
+            latents = latents * self.model.scheduler.init_noise_sigma if is_strength_max else latents
+        elif add_noise:
+            noise = latents.to(self.device)
+            latents = noise * self.model.scheduler.init_noise_sigma
+        else:
+            noise = torch.randn(shape, generator=generator, device=self.device, dtype=dtype)
+            latents = image_latents.to(self.device)
+        return latents, noise, (image_latents if return_image_latents else None)
+
+    def prepare_mask_latents(self, mask, masked_image, batch_size, height, width, dtype, seed=None):
+        """sd_unified_pipeline.py:916-976."""
+        mask = torch.nn.functional.interpolate(mask, size=(height, width)).to(device=self.device, dtype=dtype)
+        if mask.shape[0] < batch_size:
+            if batch_size % mask.shape[0] != 0:
+                raise ValueError("The passed mask and the required batch size don't match.")
+            mask = mask.repeat(batch_size // mask.shape[0], 1, 1, 1)
+        mask = torch.cat([mask] * 2) if self.do_classifier_free_guidance else mask
+        generator = None
+        if seed is not None:
+            generator = torch.Generator(device=self.device).manual_seed(int(seed))
+        masked_image_latents = masked_image if (masked_image is not None and masked_image.shape[1] == 4) else None
+        if masked_image is not None:
+            if masked_image_latents is None:
+                masked_image_latents = self._encode_vae_image(masked_image.to(device=self.device, dtype=dtype), generator)
+            if masked_image_latents.shape[0] < batch_size:
+                if batch_size % masked_image_latents.shape[0] != 0:
+                    raise ValueError("The passed images and the required batch size don't match.")
+                masked_image_latents = masked_image_latents.repeat(batch_size // masked_image_latents.shape[0], 1, 1, 1)
+            if self.do_classifier_free_guidance:
+                masked_image_latents = torch.cat([masked_image_latents] * 2)
+            masked_image_latents = masked_image_latents.to(device=self.device, dtype=dtype)
+        return mask, masked_image_latents
 
     def _encode_vae_image(self, image, generator):
         """sd_unified_pipeline.py:1017-1041."""

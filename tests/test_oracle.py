@@ -134,3 +134,29 @@ def test_pipeline_img2img_and_errors(golden):
         model.set_scheduler("nope")
     model.set_scheduler("DPM++ 2M")
     assert isinstance(model.scheduler, schedulers.DPMSolverMultistepScheduler)
+
+
+def test_pipeline_inpaint(golden):
+    """4-channel inpaint (sd_unified_pipeline.py:268-380, :492-506): outside the mask the result is
+    exactly the original image's latents after the last step; inside it is denoised."""
+    ucfg, vcfg, uw, vw, d = golden
+    model = SDModelWrapper(base=OracleUNet(ucfg, uw), vae=OracleVAE(vcfg, vw),
+                           scheduler=schedulers.DDIMScheduler(), device="cpu")
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cpu", output_type="latents")
+    neg, pos = d["pipe_embeds2b"][:1], d["pipe_embeds2b"][1:]
+    g = torch.Generator().manual_seed(9)
+    image = torch.randn(1, 3, 64, 64, generator=g).clamp(-1, 1)
+    mask = torch.zeros(1, 1, 64, 64)
+    mask[:, :, :, 32:] = 1.0                                  # repaint the right half
+    out = pipe(model, prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask,
+               num_inference_steps=3, seed=1)
+    assert out.shape == (1, 4, 8, 8) and torch.isfinite(out).all()
+    gen = torch.Generator().manual_seed(1)
+    ref_lat = model.vae.encode(image).latent_dist.sample(gen) * vcfg.scaling_factor
+    assert torch.allclose(out[..., :4], ref_lat[..., :4], atol=1e-5)       # kept region == encoded original
+    assert not torch.allclose(out[..., 4:], ref_lat[..., 4:], atol=1e-2)    # repainted region changed
+    with pytest.raises(NotImplementedError):
+        pipe(model, prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask, padding_mask_crop=8)
+    with pytest.raises(ValueError):
+        pipe(model, prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask, strength=0.1,
+             num_inference_steps=3)                            # int(3 * 0.1) = 0 steps
