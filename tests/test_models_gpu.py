@@ -268,3 +268,48 @@ def test_sdxl_full_size_unet_forward(engine_lib):
         ref = unet_ref.unet_forward(ucfg, uw, x.float(), torch.tensor(621.0), ehs.float(),
                                     {"text_embeds": added["text_embeds"].float(), "time_ids": added["time_ids"]})
     assert rel_l2(got, ref) < TOL
+
+
+def test_img2img_with_fused_lora_against_oracle(engine_lib):
+    """BASELINE.json config C5 in miniature: LoRA (r=16, alpha=r, on to_q/to_k/to_v/to_out.0 as the
+    reference trainer writes it, train_lora_pipeline.py:247-252) fused on the host, then the img2img
+    branch of the pipeline (4-channel latents passed as `image`, `denoising_start` so no device-side
+    noise is drawn) through the HIP engine vs the same pipeline code on oracle-backed doubles."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from doubles import OracleUNet, OracleVAE
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = config.tiny_unet(), config.tiny_vae()
+    base = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=41, perturb=0.1)
+    g = torch.Generator().manual_seed(3)
+    lora = {}
+    for k, w in base.items():
+        if k.endswith(("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight")):
+            mod = k[: -len(".weight")]
+            lora[f"unet.{mod}.lora.down.weight"] = torch.randn(16, w.shape[1], generator=g) * 0.05
+            lora[f"unet.{mod}.lora.up.weight"] = torch.randn(w.shape[0], 16, generator=g) * 0.05
+    fused = _f16_round(weights.fuse_lora(base, lora, adapter_weight=0.8))
+    assert not torch.equal(fused["mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight"],
+                           base["mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight"].half().float())
+    vsd = _f16_round(weights.synth_state_dict(weights.vae_manifest(vcfg), seed=42, perturb=0.1))
+    init = torch.randn(2, 4, 8, 8, generator=g).half()
+    pos = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g).half()
+    neg = torch.randn(2, 77, ucfg.cross_attention_dim, generator=g).half()
+    kw = dict(num_inference_steps=6, guidance_scale=4.0, denoising_start=0.5, strength=1.0)
+    gpu_model = SDModelWrapper(base=HipUNet2DConditionModel(ucfg).load_state_dict(fused),
+                               vae=HipAutoencoderKL(vcfg).load_state_dict(vsd), scheduler=DDIMScheduler(), device="cuda")
+    got = StableDiffusionUnifiedPipeline(True, "cuda", "latents")(
+        gpu_model, prompt_embeds=pos, negative_prompt_embeds=neg, image=init, **kw)
+    cpu_model = SDModelWrapper(base=OracleUNet(ucfg, fused), vae=OracleVAE(vcfg, vsd), scheduler=DDIMScheduler(),
+                               device="cpu")
+    ref = StableDiffusionUnifiedPipeline(True, "cpu", "latents")(
+        cpu_model, prompt_embeds=pos.float(), negative_prompt_embeds=neg.float(), image=init.float(), **kw)
+    assert got.shape == ref.shape == (2, 4, 8, 8)
+    assert rel_l2(got, ref) < TOL
+    # and the pixel-space img2img branch runs end to end on the engine (VAE encode -> noise -> loop -> decode)
+    img = torch.randn(2, 3, 64, 64, generator=g).clamp(-1, 1).half()
+    out = StableDiffusionUnifiedPipeline(True, "cuda")(gpu_model, prompt_embeds=pos, negative_prompt_embeds=neg,
+                                                       image=img, strength=0.5, num_inference_steps=4, seed=7)
+    assert out.shape == (2, 3, 64, 64) and torch.isfinite(out.float()).all()
