@@ -16,7 +16,8 @@ struct Resnet {
 };
 struct TBlock {
     NormW ln1, ln2, ln3;
-    ConvW qkv, out1, q2, kv2, out2, ff1, ff2;
+    ConvW qkv, out1, q2, out2, ff1, ff2;
+    int kv_off = 0;     // column offset of this block's [K | V] text projection in UNet::kv_all
 };
 struct Xformer {
     NormW gn;
@@ -32,8 +33,7 @@ struct VaeAttn {
 
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
                 const float* tproj, int tproj_ld);
-void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G,
-                 const half_t* ehs, int L, int ctx_dim);
+void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L);
 
 struct UNet {
     explicit UNet(const sd_unet_config& c);
@@ -49,6 +49,8 @@ struct UNet {
     long planned_key = -1;
 
     ConvW conv_in, conv_out, te1, te2, ae1, ae2, temb_stack;
+    ConvW kv_all;                       // every attn2.to_k / to_v of the model, row-concatenated
+    std::vector<std::string> kv_keys;   // (finalize only)
     NormW norm_out;
     std::vector<std::vector<Resnet>> down_res, up_res;
     std::vector<std::vector<Xformer>> down_att, up_att;
@@ -56,6 +58,7 @@ struct UNet {
     Resnet mid_r0, mid_r1;
     Xformer mid_att;
     int temb_total = 0;
+    int kv_total = 0;
 
   private:
     int pack_resnet(const std::string& p, Resnet* r, std::vector<std::string>* tw, std::vector<std::string>* tb);

@@ -162,7 +162,12 @@ int UNet::pack_xformer(const std::string& p, Xformer* x, int heads, int depth) {
         if ((rc = ws.pack_rows({q + ".attn1.to_q.weight", q + ".attn1.to_k.weight", q + ".attn1.to_v.weight"}, {}, &b.qkv))) return rc;
         if ((rc = ws.pack_conv(q + ".attn1.to_out.0", &b.out1))) return rc;
         if ((rc = ws.pack_conv(q + ".attn2.to_q", &b.q2, false))) return rc;
-        if ((rc = ws.pack_rows({q + ".attn2.to_k.weight", q + ".attn2.to_v.weight"}, {}, &b.kv2))) return rc;
+        // text K/V projections depend only on encoder_hidden_states: all of them are stacked into
+        // one GEMM (kv_all) issued once per forward instead of one small launch per block
+        b.kv_off = kv_total;
+        kv_total += 2 * x->C;
+        kv_keys.push_back(q + ".attn2.to_k.weight");
+        kv_keys.push_back(q + ".attn2.to_v.weight");
         if ((rc = ws.pack_conv(q + ".attn2.to_out.0", &b.out2))) return rc;
         if ((rc = ws.pack_geglu(q + ".ff.net.0.proj", &b.ff1))) return rc;
         if ((rc = ws.pack_conv(q + ".ff.net.2", &b.ff2))) return rc;
@@ -178,6 +183,8 @@ int UNet::finalize() {
     int rc;
     std::vector<std::string> tw, tb;
     temb_total = 0;
+    kv_total = 0;
+    kv_keys.clear();
     if ((rc = ws.pack_conv("conv_in", &conv_in))) return rc;
     if ((rc = ws.pack_conv("time_embedding.linear_1", &te1))) return rc;
     if ((rc = ws.pack_conv("time_embedding.linear_2", &te2))) return rc;
@@ -217,6 +224,8 @@ int UNet::finalize() {
     if ((rc = ws.pack_norm("conv_norm_out", &norm_out))) return rc;
     if ((rc = ws.pack_conv("conv_out", &conv_out))) return rc;
     if ((rc = ws.pack_rows(tw, tb, &temb_stack))) return rc;
+    if (!kv_keys.empty() && (rc = ws.pack_rows(kv_keys, {}, &kv_all))) return rc;
+    kv_keys.clear();
     SD_HIP_CHECK(hipDeviceSynchronize());
     ws.free_raw();
     finalized = true;
@@ -244,8 +253,7 @@ void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, 
     a.release(mk);
 }
 
-void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G,
-                 const half_t* ehs, int L, int ctx_dim) {
+void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const int C = t.C;
@@ -256,7 +264,6 @@ void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out
     op_groupnorm(c, t.gn, x, hn, N, T, G, 1e-6f, 0);
     View cur(a.alloc_h(M * C), C, C), nxt(a.alloc_h(M * C), C, C);
     op_conv(c, t.pin, hn, N, H, W, cur);
-    View ctx(const_cast<half_t*>(ehs), ctx_dim, ctx_dim);
     for (const TBlock& b : t.blocks) {
         const size_t mb = a.mark();
         View n(a.alloc_h(M * C), C, C);
@@ -270,9 +277,7 @@ void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out
         op_layernorm(c, b.ln2, t2, n, M, 1e-5f);
         View q(a.alloc_h(M * C), C, C);
         op_conv(c, b.q2, n, N, H, W, q);
-        View kv(a.alloc_h((long)N * L * 2 * C), 2 * C, 2 * C);
-        op_conv(c, b.kv2, ctx, N, L, 1, kv);
-        op_attention(c, q, kv.slice(0, C), kv.slice(C, C), att, N, T, L, t.heads, d);
+        op_attention(c, q, text_kv.slice(b.kv_off, C), text_kv.slice(b.kv_off + C, C), att, N, T, L, t.heads, d);
         View t3(a.alloc_h(M * C), C, C);
         op_conv(c, b.out2, att, N, H, W, t3, 1, 0, nullptr, 0, &t2);
         op_layernorm(c, b.ln3, t3, n, M, 1e-5f);
@@ -333,6 +338,10 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     }
     if (go && !c.err) c.err = launch_small_linear(emb, temb, temb_stack.w, temb_stack.bias, tproj, temb_total, B, temb, temb_total, 1, 0, s);
 
+    // ---- text K/V of every cross-attention block in one GEMM: [B*L, ctx] x [ctx, sum 2C] ----
+    View text_kv(a.alloc_h((long)B * L * kv_total), kv_total, kv_total);
+    op_conv(c, kv_all, View(const_cast<half_t*>(ehs), cfg.cross_attention_dim, cfg.cross_attention_dim), B, L, 1, text_kv);
+
     // ---- skip / concat buffer plan ----
     // Skip tensors are produced in down-path order and consumed by the up path in reverse; each
     // up resnet k reads cat_k = [hidden (C1) | skip (C2)].  Allocate every cat_k up front so the
@@ -386,7 +395,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
                 View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
                 run_resnet(c, r, x, B, h, w, tmp, G, eps, tproj, temb_total);
                 View dst = skip_view(skip_i);
-                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, ehs, L, cfg.cross_attention_dim);
+                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, text_kv, L);
                 a.release(mk);
                 x = dst;
             } else {
@@ -410,7 +419,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         const long M = (long)B * h * w;
         View m0(a.alloc_h(M * C), C, C), m1(a.alloc_h(M * C), C, C);
         run_resnet(c, mid_r0, x, B, h, w, m0, G, eps, tproj, temb_total);
-        run_xformer(c, mid_att, m0, B, h, w, m1, G, ehs, L, cfg.cross_attention_dim);
+        run_xformer(c, mid_att, m0, B, h, w, m1, G, text_kv, L);
         const Cat& ct = cats[0];
         View dst(ct.p, ct.c1 + ct.c2, ct.c1);
         run_resnet(c, mid_r1, m1, B, h, w, dst, G, eps, tproj, temb_total);
@@ -438,7 +447,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
             if (cfg.up_block_has_attn[i]) {
                 View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
                 run_resnet(c, r, xin, B, h, w, tmp, G, eps, tproj, temb_total);
-                run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, ehs, L, cfg.cross_attention_dim);
+                run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L);
             } else {
                 run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total);
             }
