@@ -304,8 +304,11 @@ class StableDiffusionUnifiedPipeline:
                 if clip_skip is None:
                     e = out.hidden_states[-2] if sdxl else out[0]
                 else:
+                    # transformers 4.39 (the reference's pin) nests the layers under `.text_model`;
+                    # newer releases expose `final_layer_norm` on the model itself
+                    final_ln = getattr(enc, "text_model", enc).final_layer_norm
                     e = (out.hidden_states[-(clip_skip + 2)] if sdxl
-                         else enc.text_model.final_layer_norm(out[-1][-(clip_skip + 1)]))
+                         else final_ln(out.hidden_states[-(clip_skip + 1)]))
                 embeds.append(e)
             return torch.concat(embeds, dim=-1), pooled
 
