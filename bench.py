@@ -173,7 +173,7 @@ def main():
         log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
     n_gpus = max(world, 1)
     _lib.require_gpu()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     lib = _lib.load()
@@ -247,8 +247,7 @@ def main():
         u_tf = UNET_TFLOP_PER_SAMPLE[args.preset].get(lat_hw)
         v_tf = VAE_TFLOP_PER_IMAGE.get(lat_hw)
         result = {
-            "metric": ("denoise-loop latents/s (512px, 50-step DDIM, batch 4)" if args.preset == "sd15" else
-                       f"denoise-loop latents/s ({args.res}px, {args.denoise_steps}-step {args.scheduler}, batch {B})"),
+            "metric": f"denoise-loop latents/s ({args.res}px, {args.denoise_steps}-step {args.scheduler}, batch {B})",
             "value": round(value, 4), "unit": "latents/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",

@@ -27,7 +27,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int]:
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SD_DIST_BACKEND=gloo lets several ranks rehearse on a box with fewer GPUs than ranks
+            backend = os.environ.get("SD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -50,11 +51,21 @@ def shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return t[lo:hi]
 
 
+def _host_staged() -> bool:
+    """gloo moves host memory: device tensors are staged through the CPU (rehearsal path only)."""
+    return dist.get_backend() == "gloo"
+
+
 def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0):
     """In-place broadcast of already-allocated tensors (text embeddings) from `src`."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         for t in tensors:
-            dist.broadcast(t, src=src)
+            if _host_staged() and t.is_cuda:
+                h = t.cpu()
+                dist.broadcast(h, src=src)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src)
     return tensors
 
 
@@ -68,9 +79,12 @@ def all_gather_batch(local: torch.Tensor, total: int) -> torch.Tensor:
     pad = local
     if local.shape[0] < max_n:
         pad = torch.cat([local, local.new_zeros((max_n - local.shape[0],) + tuple(local.shape[1:]))])
+    dev = pad.device
+    if _host_staged() and pad.is_cuda:
+        pad = pad.cpu()
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad.contiguous())
-    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0).to(dev)
 
 
 def barrier():
@@ -81,7 +95,7 @@ def barrier():
 def max_over_ranks(x: float, device) -> float:
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
