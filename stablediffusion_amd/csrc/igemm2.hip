@@ -25,12 +25,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW, bool STAG>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW, bool STAG, int BKT>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmParams p, float* partial,
                                                                       int k_tiles_per_split) {
-    static_assert((BM / 8) % (WAVES_M * WAVES_N) == 0, "A-tile DMA rows must divide over the waves");
+    // BKT = 32 with a 4-deep ring (prefetch distance 1.5 slabs of 64 at the same LDS footprint) was
+    // built and measured: correct, but 10-20 % slower than BKT = 64 with 2 stages (a barrier per
+    // 20 MFMAs costs more than the extra look-ahead buys); the shipped variants all use 64.
+    static_assert(BKT == 64 || BKT == 32, "K slab depth");
+    static_assert((BM / (512 / BKT)) % (WAVES_M * WAVES_N) == 0, "A-tile DMA rows must divide over the waves");
     static_assert((BM / WAVES_M) % 16 == 0 && (BN / WAVES_N) % 16 == 0, "wave tile must be MFMA-shaped");
-    static_assert(STAGES == 2 || STAGES == 3, "ring depth (a 4-deep ring measured slower: one block per CU)");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 
     // The body is device-only: clang's host pass cannot type-check the gfx950 LDS-DMA builtin
     // (16-byte size) and would silently drop the kernel's host stub.
@@ -42,11 +46,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     constexpr int TM = WTM / 16, TN = WTN / 16;
     // DMA instructions per wave per slab.  The B tile may not divide evenly over the waves
     // (160 rows / 8 waves): the first B_REM waves then issue one instruction more.
-    constexpr int A_PW = BM / 8 / NW;
-    constexpr int B_INSTR = BN / 8, B_REM = B_INSTR % NW, B_PW = (B_INSTR + NW - 1) / NW;
+    // One DMA wave-instruction moves 1 KiB = RPI tile rows of BKT halves (8 rows x 128 B or 16 x 64 B).
+    constexpr int CPR = BKT / 8;                // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;               // tile rows per DMA instruction
+    constexpr int KSTEPS = BKT / 32;            // MFMA k-steps per slab
+    constexpr int A_PW = BM / RPI / NW;
+    constexpr int B_INSTR = BN / RPI, B_REM = B_INSTR % NW, B_PW = (B_INSTR + NW - 1) / NW;
     constexpr int LPW = A_PW + B_PW;            // waves < B_REM (or all, when even)
     constexpr int LPW_LO = A_PW + B_PW - 1;     // waves >= B_REM when uneven
-    constexpr int STAGE_HALVES = (BM + BN) * BK;
+    constexpr int STAGE_HALVES = (BM + BN) * BKT;
     constexpr int LDC = BN + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* ring = reinterpret_cast<half_t*>(smem);
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
-    const int nk_total = p.K / BK;
+    const int nk_total = p.K / BKT;
     const int kt_begin = split * k_tiles_per_split;
     int nk = nk_total - kt_begin;
     if (nk > k_tiles_per_split) nk = k_tiles_per_split;
@@ -73,9 +81,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     const long wrows = ((long)p.Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, (int)(wrows * p.K * 2), 0x00020000);
 
-    // ---- per-lane source coordinates: lane -> (row = 8*instr + lane/8, chunk = (lane%8) ^ (lane/8)) ----
-    const int lrow = lane >> 3;
-    const int chunk = (lane & 7) ^ lrow;
+    // ---- per-lane source coordinates: lane -> (row = RPI*instr + lane/CPR, chunk = (lane%CPR) ^ swz(row)):
+    //      the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free, applied on the
+    //      SOURCE side (128-byte rows: chunk ^ (row & 7); 64-byte rows: chunk ^ ((row >> 1) & 3)) ----
+    auto swz = [](int r) { return BKT == 64 ? (r & 7) : ((r >> 1) & 3); };
+    const int lrow = lane / CPR;
+    const int chunk = (lane % CPR) ^ swz(lrow);
     const int OHW = p.OH * p.OW;
     const unsigned IH = (unsigned)(p.H << p.up), IW = (unsigned)(p.W << p.up);
     int a_ih[A_PW], a_iw[A_PW];   // top-left input coordinate of the row's pixel; rows >= M get a
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     unsigned a_base[A_PW];        // byte offset of (n, 0, 0, chunk), or of the row itself (pointwise)
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
-        const int m = m0 + (wave * A_PW + j) * 8 + lrow;
+        const int m = m0 + (wave * A_PW + j) * RPI + lrow;
         const bool okm = m < p.M;
         const int mm = okm ? m : 0;
         if (PW) {
@@ -105,20 +116,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     unsigned b_off[B_PW];
 #pragma unroll
     for (int j = 0; j < B_PW; ++j)
-        b_off[j] = (unsigned)((((long)(n0 + (b_first + j) * 8 + lrow)) * p.K + chunk * 8) * 2);
+        b_off[j] = (unsigned)((((long)(n0 + (b_first + j) * RPI + lrow)) * p.K + chunk * 8) * 2);
 
     // tap state of the NEXT slab to issue
     // K order = [Cin/64][KH][KW][64] (misc.hip pack_conv_kernel): taps innermost
-    int k0 = kt_begin * BK;
+    int k0 = kt_begin * BKT;
     const int taps = p.KS * p.KS;
-    int ci0 = (kt_begin / taps) * BK;
-    const int tap0 = kt_begin % taps;
+    constexpr int PER64 = 64 / BKT;             // slabs per 64-channel group (1 or 2)
+    const int g64 = kt_begin / PER64;
+    int sub = (kt_begin % PER64) * BKT;         // channel offset inside the 64-channel group
+    int ci0 = (g64 / taps) * 64;
+    const int tap0 = g64 % taps;
     int kh = tap0 / p.KS, kw = tap0 - kh * p.KS;
     const unsigned row_bytes = (unsigned)(p.ldx * 2);
 
     auto issue = [&](int slot) {
         half_t* sa = ring + slot * STAGE_HALVES;
-        half_t* sb = sa + BM * BK;
+        half_t* sb = sa + BM * BKT;
 #pragma unroll
         for (int j = 0; j < A_PW; ++j) {
             unsigned voff;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
                 const int ih = a_ih[j] + kh, iw = a_iw[j] + kw;
                 const bool ok = ((unsigned)ih < IH) & ((unsigned)iw < IW);   // negative -> huge unsigned
                 const unsigned off = a_base[j] + (unsigned)((ih >> p.up) * p.W + (iw >> p.up)) * row_bytes +
-                                     (unsigned)(ci0 * 2);
+                                     (unsigned)((ci0 + sub) * 2);
                 voff = ok ? off : kOOB;
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -140,8 +154,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rw, (__attribute__((address_space(3))) void*)(sb + (b_first + j) * 512), 16,
                     b_off[j] + (unsigned)(k0 * 2), 0, 0, 0);
-        k0 += BK;
-        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ci0 += BK; } }
+        k0 += BKT;
+        sub += BKT;
+        if (sub == 64) {
+            sub = 0;
+            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ci0 += 64; } }
+        }
     };
 
     f4 acc[TM][TN];
@@ -159,10 +177,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt must have landed; at most D-1 younger stages may stay in flight
-        if (D == 2 && kt + 1 < nk) {
-            if (b_hi) wait_vmcnt<LPW>(); else wait_vmcnt<LPW_LO>();
-        } else {
-            wait_vmcnt<0>();
+        {
+            const int rem = nk - 1 - kt;
+            if (D >= 3 && rem >= 2) {
+                if (b_hi) wait_vmcnt<2 * LPW>(); else wait_vmcnt<2 * LPW_LO>();
+            } else if (D >= 2 && rem >= 1) {
+                if (b_hi) wait_vmcnt<LPW>(); else wait_vmcnt<LPW_LO>();
+            } else {
+                wait_vmcnt<0>();
+            }
         }
         __builtin_amdgcn_s_barrier();
         // (kt + D) % STAGES == (kt - 1) % STAGES.  With STAG the second wave group (the SIMD partners
@@ -171,20 +194,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
         const bool late = STAG && wave >= NW / 2;
         if (!late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
         const half_t* cA = ring + slot * STAGE_HALVES;
-        const half_t* cB = cA + BM * BK;
+        const half_t* cB = cA + BM * BKT;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             h8 fa[TM], fb[TN];
             const int ch = ks * 4 + fq;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = wm * WTM + i * 16 + fr;
-                fa[i] = *reinterpret_cast<const h8*>(cA + r * BK + ((ch ^ (r & 7)) << 3));
+                fa[i] = *reinterpret_cast<const h8*>(cA + r * BKT + ((ch ^ swz(r)) << 3));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn * WTN + j * 16 + fr;
-                fb[j] = *reinterpret_cast<const h8*>(cB + r * BK + ((ch ^ (r & 7)) << 3));
+                fb[j] = *reinterpret_cast<const h8*>(cB + r * BKT + ((ch ^ swz(r)) << 3));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -307,23 +330,23 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG>
+template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG, int BKT>
 int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
-    constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * sizeof(half_t);
+    constexpr size_t ring = (size_t)STAGES * (BM + BN) * BKT * sizeof(half_t);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(half_t);
     constexpr size_t lds = ring > epi ? ring : epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG>),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
-    const int nk = p.K / BK;
+    const int nk = p.K / BKT;
     const int per = cdiv(nk, splits);
     const int eff_splits = cdiv(nk, per);
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
                        p, eff_splits > 1 ? partial : nullptr, per);
     SD_HIP_CHECK(hipGetLastError());
     if (eff_splits > 1) {
@@ -336,11 +359,11 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool STAG = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool STAG = false, int BKT = 64>
 int launch_v2(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     if (p.KS == 1 && p.stride == 1 && p.up == 0)
-        return launch_v2p<BM, BN, WM, WN, STAGES, true, STAG>(p, partial, splits, s);
-    return launch_v2p<BM, BN, WM, WN, STAGES, false, STAG>(p, partial, splits, s);
+        return launch_v2p<BM, BN, WM, WN, STAGES, true, STAG, BKT>(p, partial, splits, s);
+    return launch_v2p<BM, BN, WM, WN, STAGES, false, STAG, BKT>(p, partial, splits, s);
 }
 
 int g_force_variant = -1;
