@@ -79,28 +79,18 @@ def live_roofline(lib, unet, vae, B, lat_hw, ehs, device, added=None):
 def pmc_traffic_for(kernel_label: str):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
     (profiles/r01_pmc_hbm_traffic_per_launch.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE;
-    PMC passes cannot run inside the timed bench).  bench label 'igemm2<128,160,s2>' <-> rocprof
-    'igemm2_kernel<128,160,2,2,2,{true,false},false>'."""
+    PMC passes cannot run inside the timed bench).  Kernel labels are the rocprofv3 names."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_per_launch.json")
     if not os.path.exists(path):
         return None
-    import re
     data = json.load(open(path))
-    m = re.match(r"igemm2<(\d+),(\d+),(?:8w,)?s(\d)(,stag)?>", kernel_label.replace("+splitK", ""))
-    keys = []
-    if m:
-        bm, bn, st, stag = m.group(1), m.group(2), m.group(3), "true" if m.group(4) else "false"
-        keys = [k for k in data if k.startswith(f"igemm2_kernel<{bm},{bn},") and k.endswith(f",{st},true,{stag}>")
-                or k.startswith(f"igemm2_kernel<{bm},{bn},") and k.endswith(f",{st},false,{stag}>")]
-    elif kernel_label.startswith("attn_kernel"):
-        keys = [k for k in data if k == kernel_label]
-    n = sum(data[k]["launches"] for k in keys)
-    if not n:
+    e = data.get(kernel_label.replace("+splitk", ""))
+    if not e:
         return None
-    b = sum((data[k]["fetch_MB_per_launch"] + data[k]["write_MB_per_launch"]) * data[k]["launches"] for k in keys) / n
-    return {"hbm_MB_per_launch": round(b, 2), "source": "profiles/r01_pmc_hbm_traffic_per_launch.json "
-            "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled for gfx950; "
-            "average over all launches of the kernel in that run)"}
+    return {"hbm_MB_per_launch": round(e["fetch_MB_per_launch"] + e["write_MB_per_launch"], 2),
+            "source": "profiles/r01_pmc_hbm_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                      "separate passes, FETCH_SIZE doubled for gfx950; average over all launches of the kernel "
+                      "in that run)"}
 
 
 def usable_cores() -> int:

@@ -141,7 +141,7 @@ int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float 
  * the launch stream.  sd_prof_collect synchronises and returns one aggregate per kernel name:
  * algorithmic FLOPs and bytes (2*MAC; inputs + weights + outputs once), summed event time. */
 typedef struct sd_prof_entry {
-    char kernel[48];
+    char kernel[64];
     double flops;
     double bytes;
     double ms;

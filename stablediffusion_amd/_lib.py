@@ -51,7 +51,7 @@ class SdVAEConfig(C.Structure):
 
 
 class SdProfEntry(C.Structure):
-    _fields_ = [("kernel", C.c_char * 48), ("flops", C.c_double), ("bytes", C.c_double),
+    _fields_ = [("kernel", C.c_char * 64), ("flops", C.c_double), ("bytes", C.c_double),
                 ("ms", C.c_double), ("launches", C.c_int64)]
 
 

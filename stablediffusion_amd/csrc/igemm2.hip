@@ -374,9 +374,12 @@ int g_force_splits = 0;
 // Variant ids (also used by the tuner in tests/tools): keep in sync with kIgemm2Names.
 //   0: 256x128 8 waves 3 stages   1: 128x128 4 waves 2 stages   2: 128x160 4 waves 2 stages
 //   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
-static const char* kIgemm2Names[] = {"igemm2<256,128,s3>", "igemm2<128,128,s2>", "igemm2<128,160,s2>",
-                                     "igemm2<128,64,s2>",  "igemm2<64,64,s2>",   "igemm2<256,160,s3>",
-                                     "igemm2<256,128,s3,stag>", "igemm2<256,160,8w,s3,stag>"};
+// printf formats of the kernel names as rocprofv3 prints them (%s = the pointwise flag)
+static const char* kIgemm2Names[] = {
+    "igemm2_kernel<256,128,4,2,3,%s,false,64>", "igemm2_kernel<128,128,2,2,2,%s,false,64>",
+    "igemm2_kernel<128,160,2,2,2,%s,false,64>", "igemm2_kernel<128,64,2,2,2,%s,false,64>",
+    "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
+    "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>"};
 constexpr int kNumVariants = 8;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
