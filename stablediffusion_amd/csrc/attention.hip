@@ -18,8 +18,11 @@
 //   * the output rescale by exp2(m_old - m_new) is skipped (wave-uniformly) while the running max
 //     grows by less than 2^8 -- probabilities stay below 256, well inside fp16.
 //   * K / V tiles of 64 keys in LDS with row strides that are odd multiples of 32 bytes:
-//     conflict-free for both ds_read_b128 fragment reads and the transposed reads; the next tile's
-//     global loads are issued before the current tile is multiplied (register-staged prefetch).
+//     conflict-free for both ds_read_b128 fragment reads and the transposed reads.  Tiles are
+//     double-buffered in LDS and prefetched two tiles ahead through registers, so there is ONE
+//     barrier per tile (PMC showed waves 40 % of their time in s_waitcnt/barrier with two).
+//     Measured and rejected: 128-key tiles (fewer barriers, more registers: 10-30 % slower) and
+//     64 queries per wave for d = 64 / 80 (slower); d = 40 runs 64 queries per wave (QT = 4).
 //   * head dims 40 / 80 / 160 (SD1.5), 64 (SDXL), 512 (VAE), 32 / 128 (test configs); the QK^T
 //     contraction is zero-padded to a multiple of 32, the PV row tiles to a multiple of 16.
 #include "kernels.h"
@@ -27,7 +30,6 @@
 namespace sd {
 namespace {
 
-constexpr int KT = 64;  // keys per tile
 constexpr float kRescaleThreshold = 8.0f;   // log2 units
 
 constexpr int odd32_bytes(int bytes) { return ((((bytes + 31) / 32) | 1)) * 32; }
@@ -38,13 +40,16 @@ __device__ __forceinline__ unsigned pack_rtz(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-template <int D, int QT>
+template <int D, int QT, int KT>
 __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                                                    const half_t* __restrict__ k,
                                                    const half_t* __restrict__ v,
                                                    half_t* __restrict__ out, int Tq, int Tk,
                                                    int heads, long ldq, long ldk, long ldv,
                                                    long ldo, float scale_log2e) {
+    static_assert(KT == 64 || KT == 128, "keys per tile");
+    constexpr int NSUB = KT / 16;                        // 16-key subtiles per tile
+    constexpr int NKK = KT / 32;                         // 32-key k-steps of the PV product
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int KS = DK / 32;
     constexpr int DT = (D + 15) / 16;
@@ -57,6 +62,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     constexpr bool PREFETCH = D <= 160;                  // register-staged prefetch of the next tile
     constexpr int QB = 64 * QT;                          // queries per block
 
+    // With PREFETCH the K/V tiles are double-buffered in LDS (one barrier per tile); buffer b lives
+    // at smem + b * TILE_HALVES.
+    constexpr int TILE_HALVES = KT * (KSTR + VSTR);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* sK = reinterpret_cast<half_t*>(smem);
     half_t* sV = sK + KT * KSTR;
@@ -74,16 +82,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     // ---- one-time LDS padding: K columns [D, DK) = 0 (the Q pad is zero too), V columns
     //      [D, VSTR) = 0 with a column of ones at D when the denominator rides on the PV MFMA ----
     constexpr int KPAD = KSTR - D, VPAD = VSTR - D;
-    if constexpr (KPAD > 0) {
-        for (int idx = tid; idx < KT * KPAD; idx += 256) {
-            const int r = idx / KPAD, c = D + idx - r * KPAD;
-            sK[r * KSTR + c] = (half_t)0.f;
+#pragma unroll
+    for (int bufi = 0; bufi < (PREFETCH ? 2 : 1); ++bufi) {
+        if constexpr (KPAD > 0) {
+            for (int idx = tid; idx < KT * KPAD; idx += 256) {
+                const int r = idx / KPAD, c = D + idx - r * KPAD;
+                sK[bufi * TILE_HALVES + r * KSTR + c] = (half_t)0.f;
+            }
         }
-    }
-    if constexpr (VPAD > 0) {
-        for (int idx = tid; idx < KT * VPAD; idx += 256) {
-            const int r = idx / VPAD, c = D + idx - r * VPAD;
-            sV[r * VSTR + c] = (ONES && c == D) ? (half_t)1.f : (half_t)0.f;
+        if constexpr (VPAD > 0) {
+            for (int idx = tid; idx < KT * VPAD; idx += 256) {
+                const int r = idx / VPAD, c = D + idx - r * VPAD;
+                sV[bufi * TILE_HALVES + r * VSTR + c] = (ONES && c == D) ? (half_t)1.f : (half_t)0.f;
+            }
         }
     }
 
@@ -125,24 +136,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
             kreg[i] = kv; vreg[i] = vv;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int bufi) {
 #pragma unroll
         for (int i = 0; i < LIT; ++i) {
             const int idx = tid + 256 * i;
             const int r = idx / CH, c = (idx - r * CH) * 8;
             if (idx < NCH) {
-                *reinterpret_cast<h8*>(sK + r * KSTR + c) = kreg[i];
-                *reinterpret_cast<h8*>(sV + r * VSTR + c) = vreg[i];
+                *reinterpret_cast<h8*>(sK + bufi * TILE_HALVES + r * KSTR + c) = kreg[i];
+                *reinterpret_cast<h8*>(sV + bufi * TILE_HALVES + r * VSTR + c) = vreg[i];
             }
         }
     };
-    if (PREFETCH) load_tile(0);
+    if (PREFETCH) {
+        load_tile(0);
+        store_tile(0);
+        if (KT < Tk) load_tile(KT);
+        __syncthreads();                       // tile 0 and the padding of both buffers are in place
+    }
 
+    int cur = 0;
     for (int kt0 = 0; kt0 < Tk; kt0 += KT) {
-        __syncthreads();                       // previous tile fully consumed (and padding written)
         if (PREFETCH) {
-            store_tile();
+            // registers hold tile t+1: park it in the other buffer (last read one iteration ago,
+            // fenced by the barrier that closed that iteration), then fetch tile t+2
+            if (kt0 + KT < Tk) store_tile(cur ^ 1);
+            if (kt0 + 2 * KT < Tk) load_tile(kt0 + 2 * KT);
         } else {
+            __syncthreads();                   // previous tile fully consumed (and padding written)
             for (int idx = tid; idx < NCH; idx += 256) {
                 const int r = idx / CH, c = (idx - r * CH) * 8;
                 h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -153,21 +173,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                 *reinterpret_cast<h8*>(sK + r * KSTR + c) = kv;
                 *reinterpret_cast<h8*>(sV + r * VSTR + c) = vv;
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (PREFETCH && kt0 + KT < Tk) load_tile(kt0 + KT);    // in flight while this tile is multiplied
+        const half_t* cK = sK + cur * TILE_HALVES;
+        const half_t* cV = sV + cur * TILE_HALVES;
 
         // ---- S^T = K Q^T : 4 key subtiles x QT query subtiles ----
-        f4 s[4][QT];
+        f4 s[NSUB][QT];
 #pragma unroll
-        for (int ksub = 0; ksub < 4; ++ksub)
+        for (int ksub = 0; ksub < NSUB; ++ksub)
 #pragma unroll
             for (int t = 0; t < QT; ++t) s[ksub][t] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int ksub = 0; ksub < 4; ++ksub) {
-                const h8 kf = *reinterpret_cast<const h8*>(sK + (ksub * 16 + fr) * KSTR + ks * 32 + fq * 8);
+            for (int ksub = 0; ksub < NSUB; ++ksub) {
+                const h8 kf = *reinterpret_cast<const h8*>(cK + (ksub * 16 + fr) * KSTR + ks * 32 + fq * 8);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
                     s[ksub][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[ksub][t], 0, 0, 0);
@@ -175,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
         }
         if (kt0 + KT > Tk) {                   // ragged last tile: keys >= Tk never win and weigh 0
 #pragma unroll
-            for (int ksub = 0; ksub < 4; ++ksub)
+            for (int ksub = 0; ksub < NSUB; ++ksub)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (kt0 + ksub * 16 + fq * 4 + j >= Tk) {
@@ -185,14 +206,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
         }
 
         // ---- online softmax: per query = per lane column ----
-        unsigned pf[QT][2][4];                 // P^T as packed fp16 pairs: [k-step of 32 keys][4 dwords]
+        unsigned pf[QT][NKK][4];               // P^T as packed fp16 pairs: [k-step of 32 keys][4 dwords]
         bool grow = false;
         float mx[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float m = -INFINITY;
 #pragma unroll
-            for (int ksub = 0; ksub < 4; ++ksub)
+            for (int ksub = 0; ksub < NSUB; ++ksub)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) m = fmaxf(m, s[ksub][t][j]);
             m = fmaxf(m, __shfl_xor(m, 16));
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
             const float nm = -mrun[t];
             float psum = 0.f;
 #pragma unroll
-            for (int ksub = 0; ksub < 4; ++ksub) {
+            for (int ksub = 0; ksub < NSUB; ++ksub) {
                 float p[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -233,8 +254,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 #pragma unroll
         for (int i = 0; i < DT; ++i) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const half_t* a0 = sV + (kk * 32 + fq * 4 + (fr >> 2)) * VSTR + i * 16 + (fr & 3) * 4;
+            for (int kk = 0; kk < NKK; ++kk) {
+                const half_t* a0 = cV + (kk * 32 + fq * 4 + (fr >> 2)) * VSTR + i * 16 + (fr & 3) * 4;
                 const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s4v*)(a0));
                 const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -249,6 +270,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                     o[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(u.v, pb.v, o[i][t], 0, 0, 0);
                 }
             }
+        }
+        if (PREFETCH) {
+            __syncthreads();     // the one barrier per tile: publishes tile t+1, retires buffer `cur`
+            cur ^= 1;
         }
     }
 
@@ -280,20 +305,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     }
 }
 
-template <int D, int QT>
+template <int D, int QT, int KT>
 int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq, int Tk,
                 int heads, long ldq, long ldk, long ldv, long ldo, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int DT = (D + 15) / 16;
-    constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2));
+    constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT>),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
-    hipLaunchKernelGGL((attn_kernel<D, QT>), dim3(cdiv(Tq, 64 * QT), B * heads), dim3(256), lds, s, q, k, v,
+    hipLaunchKernelGGL((attn_kernel<D, QT, KT>), dim3(cdiv(Tq, 64 * QT), B * heads), dim3(256), lds, s, q, k, v,
                        out, Tq, Tk, heads, ldq, ldk, ldv, ldo, scale_log2e);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
@@ -309,16 +334,16 @@ int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* 
                      int Tk, int heads, int d, long ldq, long ldk, long ldv, long ldo, hipStream_t s) {
     if ((ldq | ldk | ldv | ldo) % 8 != 0) { set_error("attention: row strides must be multiples of 8"); return 1; }
     if (Tk <= 0 || Tq <= 0) return 0;
-#define SD_ATTN_CASE(DD, QQ) \
-    case DD: return launch_attn<DD, QQ>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, s)
+#define SD_ATTN_CASE(DD, QQ, KK) \
+    case DD: return launch_attn<DD, QQ, KK>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, s)
     switch (d) {
-        SD_ATTN_CASE(32, 2);
-        SD_ATTN_CASE(40, 2);
-        SD_ATTN_CASE(64, 2);
-        SD_ATTN_CASE(80, 2);
-        SD_ATTN_CASE(128, 2);
-        SD_ATTN_CASE(160, 2);
-        SD_ATTN_CASE(512, 1);
+        SD_ATTN_CASE(32, 2, 64);
+        SD_ATTN_CASE(40, 4, 64);
+        SD_ATTN_CASE(64, 2, 64);
+        SD_ATTN_CASE(80, 2, 64);
+        SD_ATTN_CASE(128, 2, 64);
+        SD_ATTN_CASE(160, 2, 64);
+        SD_ATTN_CASE(512, 1, 64);
         default:
             set_error("attention: unsupported head dim " + std::to_string(d));
             return 4;
