@@ -154,6 +154,7 @@ def main():
                     help="sd15 = BASELINE.json metric (C2); sdxl with --res 1024 --batch 2 --denoise-steps 30 "
                          "--scheduler 'DPM++ 2M' = config C4")
     ap.add_argument("--scheduler", default="DDIM", choices=["DDIM", "DPM++ 2M", "euler"])
+    ap.add_argument("--graph", action="store_true", help="replay the UNet forward from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -169,6 +170,8 @@ def main():
     lib = _lib.load()
 
     ucfg, vcfg, usd, vsd, unet, vae = build_models(device, args.preset)
+    if args.graph:
+        unet.use_graph(True)
     model = SDModelWrapper(base=unet, vae=vae, scheduler=DDIMScheduler(), device=str(device),
                            model_type=args.preset)
     model.set_scheduler(args.scheduler)
@@ -246,7 +249,7 @@ def main():
                                    f"batch {B}/GPU, CFG on (UNet batch {2 * B}), UNet + VAE decode HIP kernels",
                        "global_batch": total, "parallelism": f"dp{n_gpus}", "guidance_scale": args.guidance},
             "unet_forward_ms": round(unet_ms, 3), "vae_decode_ms": round(vae_ms, 3),
-            "outputs_finite": finite,
+            "outputs_finite": finite, "unet_hipgraph": bool(args.graph),
         }
         if u_tf and v_tf:
             tflop = args.denoise_steps * 2 * B * u_tf + B * v_tf     # per GPU per pass

@@ -76,6 +76,11 @@ int sd_unet_forward(sd_unet* u, const void* sample, const float* timesteps, cons
                            ehs_len, static_cast<const half_t*>(add_text), add_time_ids,
                            static_cast<half_t*>(out), B, H, W, static_cast<hipStream_t>(stream));
 }
+int sd_unet_use_graph(sd_unet* u, int enable) {
+    if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
+    u->impl.graph_enabled = enable != 0;
+    return SD_OK;
+}
 int sd_unet_memory(const sd_unet* u, int64_t* weight_bytes, int64_t* workspace_bytes) {
     if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
     if (weight_bytes) *weight_bytes = u->impl.ws.packed_bytes();

@@ -48,6 +48,22 @@ struct UNet {
     bool finalized = false;
     long planned_key = -1;
 
+    // ---- optional hipGraph replay of the whole forward (sd_unet_use_graph) ----
+    // One captured graph per input shape; inputs / output are staged through engine-owned buffers so
+    // the captured pointers stay valid whatever tensors the caller passes.  The ~480 launches of a
+    // forward then cost the host one hipGraphLaunch (CPU time per step 2 ms -> ~0.02 ms); GPU time is
+    // unchanged (kernel boundaries cost the same under a graph, MI355X_MICROARCH.md price list).
+    bool graph_enabled = false;
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    long graph_key = -1;
+    char* io_slab = nullptr;
+    size_t io_cap = 0;
+    int forward_graph(const half_t* sample, const float* timesteps, const half_t* ehs, int L, const half_t* add_text,
+                      const float* add_time_ids, half_t* out, int B, int H, int W, hipStream_t stream);
+    ~UNet();
+
     ConvW conv_in, conv_out, te1, te2, ae1, ae2, temb_stack;
     ConvW kv_all;                       // every attn2.to_k / to_v of the model, row-concatenated
     std::vector<std::string> kv_keys;   // (finalize only)

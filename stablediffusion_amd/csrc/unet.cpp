@@ -478,11 +478,94 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     return c.err;
 }
 
+UNet::~UNet() {
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    if (gstream) (void)hipStreamDestroy(gstream);
+    if (io_slab) (void)hipFree(io_slab);
+}
+
+// Graph path: stage I/O through engine-owned buffers, capture the forward once per shape on an
+// engine-owned stream, afterwards replay it with one hipGraphLaunch fenced against the caller's
+// stream by two events.
+int UNet::forward_graph(const half_t* sample, const float* timesteps, const half_t* ehs, int L,
+                        const half_t* add_text, const float* add_time_ids, half_t* out, int B, int H, int W,
+                        hipStream_t stream) {
+    const bool sdxl = cfg.addition_time_embed_dim > 0;
+    const int pdim = sdxl ? cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim : 0;
+    auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+    const size_t n_sample = up((size_t)B * cfg.in_channels * H * W * 2), n_t = up((size_t)B * 4);
+    const size_t n_ehs = up((size_t)B * L * cfg.cross_attention_dim * 2), n_text = up((size_t)B * pdim * 2);
+    const size_t n_ids = up((size_t)B * 6 * 4), n_out = up((size_t)B * cfg.out_channels * H * W * 2);
+    const size_t need = n_sample + n_t + n_ehs + n_text + n_ids + n_out;
+    if (!gstream) {
+        SD_HIP_CHECK(hipStreamCreateWithFlags(&gstream, hipStreamNonBlocking));
+        SD_HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        SD_HIP_CHECK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    }
+    if (need > io_cap) {
+        SD_HIP_CHECK(hipDeviceSynchronize());
+        if (io_slab) (void)hipFree(io_slab);
+        io_slab = nullptr; io_cap = 0; graph_key = -1;
+        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&io_slab), need));
+        io_cap = need;
+    }
+    char* ptr = io_slab;
+    half_t* g_sample = reinterpret_cast<half_t*>(ptr); ptr += n_sample;
+    float* g_t = reinterpret_cast<float*>(ptr); ptr += n_t;
+    half_t* g_ehs = reinterpret_cast<half_t*>(ptr); ptr += n_ehs;
+    half_t* g_text = sdxl ? reinterpret_cast<half_t*>(ptr) : nullptr; ptr += n_text;
+    float* g_ids = sdxl ? reinterpret_cast<float*>(ptr) : nullptr; ptr += n_ids;
+    half_t* g_out = reinterpret_cast<half_t*>(ptr);
+    SD_HIP_CHECK(hipMemcpyAsync(g_sample, sample, (size_t)B * cfg.in_channels * H * W * 2, hipMemcpyDeviceToDevice, stream));
+    SD_HIP_CHECK(hipMemcpyAsync(g_t, timesteps, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
+    SD_HIP_CHECK(hipMemcpyAsync(g_ehs, ehs, (size_t)B * L * cfg.cross_attention_dim * 2, hipMemcpyDeviceToDevice, stream));
+    if (sdxl) {
+        if (!add_text || !add_time_ids) { set_error("unet: add_text / add_time_ids required for text_time conditioning"); return 1; }
+        SD_HIP_CHECK(hipMemcpyAsync(g_text, add_text, (size_t)B * pdim * 2, hipMemcpyDeviceToDevice, stream));
+        SD_HIP_CHECK(hipMemcpyAsync(g_ids, add_time_ids, (size_t)B * 6 * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    const long key = ((long)B << 40) ^ ((long)H << 20) ^ (long)W ^ ((long)L << 52);
+    int rc = 0;
+    if (key != graph_key || !gexec) {
+        // (re)plan + one eager run on the caller's stream: sets every kernel's LDS attribute (not
+        // allowed while capturing) and produces this call's result
+        graph_enabled = false;
+        rc = forward(g_sample, g_t, g_ehs, L, g_text, g_ids, g_out, B, H, W, stream);
+        graph_enabled = true;
+        if (rc) return rc;
+        if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        SD_HIP_CHECK(hipStreamBeginCapture(gstream, hipStreamCaptureModeRelaxed));
+        Ctx ctx{&arena, gstream, false};
+        arena.begin(false);
+        rc = run(ctx, g_sample, g_t, g_ehs, L, g_text, g_ids, g_out, B, H, W);
+        hipError_t e = hipStreamEndCapture(gstream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); return 3; }
+        e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { gexec = nullptr; set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); return 3; }
+        graph_key = key;
+    } else {
+        SD_HIP_CHECK(hipEventRecord(ev_in, stream));
+        SD_HIP_CHECK(hipStreamWaitEvent(gstream, ev_in, 0));
+        SD_HIP_CHECK(hipGraphLaunch(gexec, gstream));
+        SD_HIP_CHECK(hipEventRecord(ev_out, gstream));
+        SD_HIP_CHECK(hipStreamWaitEvent(stream, ev_out, 0));
+    }
+    SD_HIP_CHECK(hipMemcpyAsync(out, g_out, (size_t)B * cfg.out_channels * H * W * 2, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
 int UNet::forward(const half_t* sample, const float* timesteps, const half_t* ehs, int L, const half_t* add_text,
                   const float* add_time_ids, half_t* out, int B, int H, int W, hipStream_t stream) {
     if (!finalized) { set_error("unet: forward before finalize"); return 2; }
     const int div = 1 << (cfg.num_blocks - 1);
     if (B <= 0 || H % div != 0 || W % div != 0) { set_error("unet: H and W must be divisible by 2^(blocks-1)"); return 1; }
+    if (graph_enabled && !prof_enabled())
+        return forward_graph(sample, timesteps, ehs, L, add_text, add_time_ids, out, B, H, W, stream);
     const long key = ((long)B << 40) ^ ((long)H << 20) ^ (long)W ^ ((long)L << 52);
     if (key != planned_key) {
         Ctx dry{&arena, stream, true};

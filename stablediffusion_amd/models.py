@@ -124,6 +124,11 @@ class HipUNet2DConditionModel:
         _lib.check(self._lib.sd_unet_memory(self._h, C.byref(w), C.byref(s)), "sd_unet_memory")
         return w.value, s.value
 
+    def use_graph(self, enable: bool = True):
+        """Replay the forward from a captured hipGraph (one host call per step instead of ~480)."""
+        _lib.check(self._lib.sd_unet_use_graph(self._h, int(bool(enable))), "sd_unet_use_graph")
+        return self
+
     # -- reference surface ---------------------------------------------------------------------
     def to(self, device=None, dtype=None):
         if device is not None and torch.device(device).type != "cuda":

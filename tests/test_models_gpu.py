@@ -344,3 +344,20 @@ def test_sd15_full_size_odd_shapes_are_finite_and_deterministic(engine_lib):
         assert a.shape == (B, 4, H, W) and torch.isfinite(a.float()).all()
         assert torch.equal(a, b)
         assert 0.05 < a.float().std().item() < 20.0
+
+
+def test_unet_hipgraph_replay_is_bitwise_eager(engine_lib):
+    """sd_unet_use_graph: captured-graph replay (staged I/O, event fences) == eager launches, across
+    repeated calls with fresh tensors, a shape change (re-capture) and back."""
+    cfg = config.tiny_unet()
+    sd = _f16_round(weights.synth_state_dict(weights.unet_manifest(cfg), seed=61, perturb=0.1))
+    eager = HipUNet2DConditionModel(cfg).load_state_dict(sd)
+    graph = HipUNet2DConditionModel(cfg).load_state_dict(sd).use_graph(True)
+    g = torch.Generator().manual_seed(4)
+    for (B, H, W) in [(2, 16, 16), (2, 16, 16), (2, 16, 16), (4, 8, 8), (2, 16, 16)]:
+        x = torch.randn(B, 4, H, W, generator=g).half().cuda()
+        ehs = torch.randn(B, 77, cfg.cross_attention_dim, generator=g).half().cuda()
+        t = torch.rand(B, generator=g) * 999
+        a = eager(x, t, ehs)[0]
+        b = graph(x.clone(), t.clone(), ehs.clone())[0]
+        assert torch.equal(a, b), (B, H, W)
