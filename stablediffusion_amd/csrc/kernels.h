@@ -65,7 +65,7 @@ int launch_timestep_sinusoid(const float* t, int t_stride, float* out, int count
 // y[b, n] = bias[n] + sum_k act(x[b, k]) * W[n, k]  for small b (time-embedding MLPs); fp32 in/out.
 int launch_small_linear(const float* x, long ldx, const half_t* w, const float* bias, float* y,
                         long ldy, int B, int K, int Nout, int silu_in, int silu_out, hipStream_t s);
-int launch_add_f32(float* y, const float* x, long n, hipStream_t s);
+int launch_add_f32(float* y, const float* x, long n, int silu, hipStream_t s);   // y = act(y + x), x may be null
 int launch_f16_to_f32(const half_t* x, float* y, long n, hipStream_t s);
 int launch_f32_to_f16(const float* x, half_t* y, long n, hipStream_t s);
 // NCHW fp16 [N,C,H,W] -> im2col rows [N*H*W, Kpad] for a 3x3 pad-1 conv with tiny C (k=(kh,kw,c)).

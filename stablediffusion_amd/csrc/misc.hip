@@ -22,55 +22,75 @@ __global__ void sinusoid_kernel(const float* __restrict__ t, int t_stride, float
     if (flip) { o[f] = cs; o[half + f] = sn; } else { o[f] = sn; o[half + f] = cs; }
 }
 
-// y[b, n] = bias[n] + sum_k act(x[b,k]) W[n,k]; one wave per output column, batch chunked by 8.
+// y[b, n] = bias[n] + sum_k act(x[b,k]) W[n,k] for a handful of rows b (time-embedding MLPs).
+// Weight-bandwidth bound (the stacked time_emb_proj matrix is 67 MB): one wave owns SL_COLS output
+// columns so it keeps SL_COLS independent 16-byte weight loads in flight per lane; the activation
+// rows (a few KB) are re-read from L1/L2.  Batch chunked by 8.
 constexpr int SL_MAXB = 8;
+constexpr int SL_COLS = 4;
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, long ldx,
                                                            const half_t* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ y, long ldy, int B,
                                                            int K, int Nout, int silu_in, int silu_out) {
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= Nout) return;
-    const half_t* wr = w + (long)n * K;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SL_COLS;
+    if (n0 >= Nout) return;
     for (int b0 = 0; b0 < B; b0 += SL_MAXB) {
-        float acc[SL_MAXB];
+        float acc[SL_COLS][SL_MAXB];
 #pragma unroll
-        for (int b = 0; b < SL_MAXB; ++b) acc[b] = 0.f;
+        for (int c = 0; c < SL_COLS; ++c)
+#pragma unroll
+            for (int b = 0; b < SL_MAXB; ++b) acc[c][b] = 0.f;
         for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
-            const h8 wv = *reinterpret_cast<const h8*>(wr + k0);
+            h8 wv[SL_COLS];
+#pragma unroll
+            for (int c = 0; c < SL_COLS; ++c) {
+                const int n = n0 + c < Nout ? n0 + c : Nout - 1;
+                wv[c] = *reinterpret_cast<const h8*>(w + (long)n * K + k0);
+            }
 #pragma unroll
             for (int b = 0; b < SL_MAXB; ++b) {
                 if (b0 + b < B) {
                     const float* xr = x + (long)(b0 + b) * ldx + k0;
                     const f4 x0 = *reinterpret_cast<const f4*>(xr);
                     const f4 x1 = *reinterpret_cast<const f4*>(xr + 4);
+                    float a[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float a0 = x0[e], a1 = x1[e];
-                        if (silu_in) { a0 = silu_f(a0); a1 = silu_f(a1); }
-                        acc[b] += a0 * (float)wv[e] + a1 * (float)wv[e + 4];
+                        a[e] = silu_in ? silu_f(x0[e]) : x0[e];
+                        a[e + 4] = silu_in ? silu_f(x1[e]) : x1[e];
                     }
+#pragma unroll
+                    for (int c = 0; c < SL_COLS; ++c)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[c][b] += a[e] * (float)wv[c][e];
                 }
             }
         }
 #pragma unroll
-        for (int b = 0; b < SL_MAXB; ++b) {
-            float a = acc[b];
+        for (int c = 0; c < SL_COLS; ++c)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-            if (lane == 0 && b0 + b < B) {
-                a += bias ? bias[n] : 0.f;
-                if (silu_out) a = silu_f(a);
-                y[(long)(b0 + b) * ldy + n] = a;
+            for (int b = 0; b < SL_MAXB; ++b) {
+                float a = acc[c][b];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (lane == 0 && b0 + b < B && n0 + c < Nout) {
+                    a += bias ? bias[n0 + c] : 0.f;
+                    if (silu_out) a = silu_f(a);
+                    y[(long)(b0 + b) * ldy + n0 + c] = a;
+                }
             }
-        }
     }
 }
 
-__global__ void add_f32_kernel(float* y, const float* x, long n) {
+// y = act(y + x): the SDXL `emb + aug_emb`, and (x == nullptr) a plain in-place SiLU.
+__global__ void add_f32_kernel(float* y, const float* x, long n, int silu) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += x[i];
+    if (i < n) {
+        float v = y[i] + (x ? x[i] : 0.f);
+        y[i] = silu ? silu_f(v) : v;
+    }
 }
 __global__ void f16_to_f32_kernel(const half_t* x, float* y, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,14 +218,14 @@ int launch_timestep_sinusoid(const float* t, int t_stride, float* out, int count
 int launch_small_linear(const float* x, long ldx, const half_t* w, const float* bias, float* y, long ldy,
                         int B, int K, int Nout, int silu_in, int silu_out, hipStream_t s) {
     if (K % 8 != 0 || ldx % 4 != 0) { set_error("small_linear: K%8, ldx%4"); return 1; }
-    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(Nout, 4)), dim3(256), 0, s, x, ldx, w, bias, y, ldy, B, K,
+    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(Nout, 4 * SL_COLS)), dim3(256), 0, s, x, ldx, w, bias, y, ldy, B, K,
                        Nout, silu_in, silu_out);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-int launch_add_f32(float* y, const float* x, long n, hipStream_t s) {
-    hipLaunchKernelGGL(add_f32_kernel, grid1d(n), dim3(256), 0, s, y, x, n);
+int launch_add_f32(float* y, const float* x, long n, int silu, hipStream_t s) {
+    hipLaunchKernelGGL(add_f32_kernel, grid1d(n), dim3(256), 0, s, y, x, n, silu);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

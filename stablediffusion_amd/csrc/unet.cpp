@@ -334,9 +334,13 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         }
         if (go && !c.err) c.err = launch_small_linear(addin, pin, ae1.w, ae1.bias, a1, temb, B, pin, temb, 0, 1, s);
         if (go && !c.err) c.err = launch_small_linear(a1, temb, ae2.w, ae2.bias, aug, temb, B, temb, temb, 0, 0, s);
-        if (go && !c.err) c.err = launch_add_f32(emb, aug, (long)B * temb, s);
+        if (go && !c.err) c.err = launch_add_f32(emb, aug, (long)B * temb, 1, s);      // silu(emb + aug_emb)
+    } else {
+        if (go && !c.err) c.err = launch_add_f32(emb, nullptr, (long)B * temb, 1, s);  // silu(emb)
     }
-    if (go && !c.err) c.err = launch_small_linear(emb, temb, temb_stack.w, temb_stack.bias, tproj, temb_total, B, temb, temb_total, 1, 0, s);
+    // every resnet consumes the embedding only as time_emb_proj(silu(emb)): the SiLU is applied once
+    // here instead of inside the weight-bandwidth-bound stacked GEMV
+    if (go && !c.err) c.err = launch_small_linear(emb, temb, temb_stack.w, temb_stack.bias, tproj, temb_total, B, temb, temb_total, 0, 0, s);
 
     // ---- text K/V of every cross-attention block in one GEMM: [B*L, ctx] x [ctx, sum 2C] ----
     View text_kv(a.alloc_h((long)B * L * kv_total), kv_total, kv_total);
