@@ -239,7 +239,17 @@ class StableDiffusionUnifiedPipeline:
         prompt_embeds = prompt_embeds.to(self.device)
 
         # ---- denoising loop (:465-507) ----
-        for i, t in enumerate(timesteps):
+        # The reference iterates over the device tensor `timesteps`; reading each element on the host
+        # (scheduler.step does int(t)) is a stream-ordered device->host copy, i.e. a full sync behind
+        # the UNet forward of every step.  One copy of the schedule to the host before the loop
+        # removes those 50 bubbles; the values are the same.
+        timesteps_host = [float(v) for v in timesteps.tolist()]
+        fused_step = self._fused_ddim_step_available(model, latents)
+        for i, t in enumerate(timesteps_host):
+            if fused_step:
+                latents = self._fused_cfg_ddim_iteration(model, latents, t, prompt_embeds, cross_attention_kwargs,
+                                                         added_cond_kwargs, guidance_scale)
+                continue
             latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
             latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
             if self.is_inpaint and num_channels_unet == 9:
@@ -255,9 +265,9 @@ class StableDiffusionUnifiedPipeline:
             if self.is_inpaint and num_channels_unet == 4:          # :492-506
                 init_latents_proper = image_latents
                 init_mask = mask.chunk(2)[0] if self.do_classifier_free_guidance else mask
-                if i < len(timesteps) - 1:
+                if i < len(timesteps_host) - 1:
                     init_latents_proper = model.scheduler.add_noise(init_latents_proper, noise,
-                                                                    torch.as_tensor([timesteps[i + 1]]))
+                                                                    torch.as_tensor([timesteps_host[i + 1]]))
                 latents = ((1 - init_mask) * init_latents_proper.float() + init_mask * latents.float()).to(latents.dtype)
 
         # ---- decode (:511-529) ----
@@ -279,6 +289,37 @@ class StableDiffusionUnifiedPipeline:
         return images
 
     # ------------------------------------------------------------------------------------------
+    def _fused_ddim_step_available(self, model, latents) -> bool:
+        """CFG combine + DDIM update as ONE device kernel each side of the UNet:
+        the scheduler still computes its coefficients on the host (`DDIMScheduler.step_coefficients`),
+        the engine applies `x <- c_x x + c_eps (u + g (t - u))` (`sd_cfg_ddim_step`).  Only for the
+        plain txt2img / img2img loop with CFG on the HIP engine; everything else takes the generic path."""
+        return (self.do_classifier_free_guidance and not self.is_inpaint
+                and isinstance(model.scheduler, _sched.DDIMScheduler)
+                and hasattr(model.base, "_lib") and latents.is_cuda and latents.dtype == torch.float16)
+
+    def _fused_cfg_ddim_iteration(self, model, latents, t, prompt_embeds, cross_attention_kwargs, added_cond_kwargs,
+                                  guidance_scale):
+        import ctypes as C
+        lib = model.base._lib
+        latents = latents.contiguous()
+        B = latents.shape[0]
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lat2 = torch.empty((2 * B,) + tuple(latents.shape[1:]), device=latents.device, dtype=latents.dtype)
+        rc = lib.sd_cfg_duplicate(C.c_void_p(latents.data_ptr()), C.c_void_p(lat2.data_ptr()),
+                                  latents[0].numel(), B, 1.0, st)
+        if rc:
+            raise RuntimeError(lib.sd_last_error().decode())
+        noise_pred = model.base(lat2, t, prompt_embeds, cross_attention_kwargs=cross_attention_kwargs,
+                                added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+        c_x, c_eps = model.scheduler.step_coefficients(t)
+        out = latents.clone()
+        rc = lib.sd_cfg_ddim_step(C.c_void_p(noise_pred.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),
+                                  float(guidance_scale), c_x, c_eps, st)
+        if rc:
+            raise RuntimeError(lib.sd_last_error().decode())
+        return out
+
     def encode_prompt(self, prompt, prompt_2=None, negative_prompt=None, negative_prompt_2=None,
                       num_images_per_prompt=1, lora_scale=None, clip_skip=None):
         """sd_unified_pipeline.py:532-719: CLIP stays host PyTorch-ROCm (north_star)."""
