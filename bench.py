@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--scheduler", default="DDIM", choices=["DDIM", "DPM++ 2M", "euler"])
     ap.add_argument("--graph", action="store_true", help="replay the UNet forward from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true",
+                    help="skip the extra 4x128x128-latent (1024 px) pass reported under `extra`")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -214,6 +216,33 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = total * args.steps / dt
 
+    # north_star also asks for the 4x128x128-latent input: one warm-up + one timed pass of the same
+    # loop at 2x the resolution (reported under `extra`, never mixed into `value`)
+    large = None
+    if not args.no_large and args.preset == "sd15" and args.res == 512:
+        lres, lhw = 2 * args.res, 2 * lat_hw
+        lat_big = torch.randn(total, 4, lhw, lhw, generator=torch.Generator().manual_seed(0)).half().to(device)
+
+        def big_pass():
+            return sdd.sharded_txt2img(pipe, model, lat_big, pe_full, ne_full, rank, n_gpus, pooled, npooled,
+                                       num_inference_steps=args.denoise_steps, guidance_scale=args.guidance,
+                                       height=lres, width=lres)
+        big_pass()
+        sdd.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        big = big_pass()
+        torch.cuda.synchronize(); sdd.barrier()
+        dt_big = sdd.max_over_ranks(time.perf_counter() - t1, device)
+        u128, v128 = UNET_TFLOP_PER_SAMPLE["sd15"].get(lhw), VAE_TFLOP_PER_IMAGE.get(lhw)
+        large = {"workload": f"SD1.5 {lres}x{lres} ({B}x4x{lhw}x{lhw} latents/GPU), {args.denoise_steps}-step "
+                             f"{args.scheduler}, CFG on", "latents_per_s": round(total / dt_big, 4),
+                 "ms_per_pass": round(dt_big * 1e3, 2), "passes_timed": 1,
+                 "outputs_finite": bool(torch.isfinite(big.float()).all().item())}
+        if u128 and v128:
+            tf = args.denoise_steps * 2 * B * u128 + B * v128
+            large["whole_path_mfma_frac"] = round(tf / dt_big / MFMA_PEAK_TFLOPS, 4)
+        del big, lat_big
+
     # UNet-only / VAE-only times (per GPU), same shapes as the loop
     x8 = torch.randn(2 * B, 4, lat_hw, lat_hw, device=device, dtype=torch.float16)
     e8 = torch.cat([ne_full[:B], pe_full[:B]])
@@ -250,6 +279,7 @@ def main():
                        "global_batch": total, "parallelism": f"dp{n_gpus}", "guidance_scale": args.guidance},
             "unet_forward_ms": round(unet_ms, 3), "vae_decode_ms": round(vae_ms, 3),
             "outputs_finite": finite, "unet_hipgraph": bool(args.graph),
+            "extra": {"latents_4x128x128": large},
         }
         if u_tf and v_tf:
             tflop = args.denoise_steps * 2 * B * u_tf + B * v_tf     # per GPU per pass
