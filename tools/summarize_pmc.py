@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection.csv (two separate passes) ->
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE output (counter_collection.csv or the rocpd *_results.db; two separate passes) ->
 profiles/r01_pmc_hbm_traffic_per_launch.json, keyed by the kernel names bench.py reports.
 FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of wide coalesced reads
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
@@ -8,6 +8,7 @@ import csv
 import glob
 import json
 import re
+import sqlite3
 import sys
 
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -20,6 +21,12 @@ def agg(d, counter):
             if r["Counter_Name"] == counter:
                 a[r["Kernel_Name"]][0] += float(r["Counter_Value"])
                 a[r["Kernel_Name"]][1] += 1
+    for path in glob.glob(d + "/*/*_results.db") + glob.glob(d + "/*_results.db"):
+        db = sqlite3.connect(path)
+        for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?",
+                                      (counter,)):
+            a[name][0] += float(value)
+            a[name][1] += 1
     return a
 
 
