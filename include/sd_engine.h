@@ -175,6 +175,10 @@ int sd_bench_conv2d(const void* x_nhwc, const void* w_oihw, void* y_nhwc, int N,
 /* GroupNorm (+ optional SiLU) on NHWC f16, fp32 statistics. */
 int sd_op_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
                     int N, int HW, int C, int groups, float eps, int silu, void* stream);
+/* Same operator, timed like sd_bench_conv2d (scratch allocated once, `iters` launches between HIP events). */
+int sd_bench_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
+                       int N, int HW, int C, int groups, float eps, int silu, int iters,
+                       float* ms_per_launch, void* stream);
 /* LayerNorm over the last dim of [rows, C] f16. */
 int sd_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C,
                     float eps, void* stream);

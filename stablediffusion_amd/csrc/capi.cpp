@@ -272,6 +272,34 @@ int sd_op_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, 
     return rc;
 }
 
+int sd_bench_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int N, int HW, int C,
+                       int groups, float eps, int silu, int iters, float* ms_per_launch, void* stream) {
+    if (iters < 1 || !ms_per_launch) { set_error("sd_bench_groupnorm: bad arguments"); return SD_ERR_INVALID; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* scratch = nullptr;
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t)gn_scratch_floats(N, HW, C, groups) * 4));
+    hipEvent_t e0, e1;
+    SD_HIP_CHECK(hipEventCreate(&e0));
+    SD_HIP_CHECK(hipEventCreate(&e1));
+    int rc = 0;
+    for (int i = 0; i < iters + 2 && !rc; ++i) {
+        if (i == 2) (void)hipEventRecord(e0, s);
+        rc = launch_groupnorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),
+                              static_cast<const float*>(beta_f32), static_cast<half_t*>(y), C, N, HW, C, groups,
+                              eps, silu, scratch, s);
+    }
+    (void)hipEventRecord(e1, s);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    *ms_per_launch = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
 int sd_op_layernorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int rows, int C, float eps,
                     void* stream) {
     return launch_layernorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),

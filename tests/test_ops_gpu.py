@@ -107,7 +107,12 @@ def test_conv_geglu(engine_lib):
 
 @pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 256, 64, 1, 1e-5), (2, 1024, 320, 1, 1e-5),
                                              (1, 64, 1920, 1, 1e-5), (3, 100, 128, 0, 1e-6),
-                                             (1, 4096, 2560, 1, 1e-5), (2, 33, 960, 0, 1e-6)])
+                                             (1, 4096, 2560, 1, 1e-5), (2, 33, 960, 0, 1e-6),
+                                             # single-pass (register-resident) form: every unit width / block shape
+                                             (2, 64, 1280, 1, 1e-5), (2, 64, 2560, 1, 1e-5), (2, 256, 640, 1, 1e-5),
+                                             (2, 256, 1920, 1, 1e-5), (2, 256, 2560, 0, 1e-5), (2, 1024, 640, 1, 1e-5),
+                                             (1, 1024, 1920, 1, 1e-5), (2, 1024, 1280, 0, 1e-6), (2, 900, 512, 1, 1e-6),
+                                             (1, 1, 320, 1, 1e-5), (2, 4096, 320, 1, 1e-5)])
 def test_groupnorm(engine_lib, N, HW, C, silu, eps):
     g = torch.Generator().manual_seed(C + HW)
     x = (torch.randn(N, HW, C, generator=g) * 1.5 + 0.7).half()
