@@ -140,6 +140,15 @@ int sd_cfg_duplicate(const void* latents, void* out2b, int64_t n_per_batch, int 
 int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float guidance_scale,
                      float c_x, float c_eps, void* stream);
 
+/* The same for every scheduler of the reference's registry (stable_diffusion.py:199-227) whose update
+ * is linear in (x, eps, previous x0 prediction) -- DDIM, Euler, DPM-Solver++(2M):
+ *   eps = u + g (t - u);  x0 = h_x x + h_eps eps;  x <- c_x x + c_eps eps + c_hist hist;  hist <- x0
+ * hist_f32 [n] is the scheduler's history (nullable: then c_hist / h_* are ignored).  Coefficients
+ * come from the host scheduler (schedulers.py `fused_plan`), replacing scheduler.step at :489. */
+int sd_cfg_linear_step(const void* noise_pred_2b, void* latents, float* hist_f32, int64_t n,
+                       float guidance_scale, float c_x, float c_eps, float c_hist, float h_x, float h_eps,
+                       void* stream);
+
 /* -- per-kernel timing for bench.py's live roofline ----------------------------------------- */
 /* While enabled, every conv / norm / attention launch of the models is bracketed by HIP events on
  * the launch stream.  sd_prof_collect synchronises and returns one aggregate per kernel name:

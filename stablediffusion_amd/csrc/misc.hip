@@ -203,6 +203,25 @@ __global__ void cfg_ddim_kernel(const half_t* __restrict__ eps2b, half_t* __rest
     lat[i] = (half_t)(cx * (float)lat[i] + ce * e);
 }
 
+// Any scheduler whose update is linear in (x, eps, previous x0 prediction): DDIM, Euler, DPM-Solver++(2M).
+//   eps = u + g (t - u);  x0 = hx x + he eps;  x <- cx x + ce eps + ch hist;  hist <- x0
+// (hist fp32, like the host schedulers keep their history; null when the scheduler has none)
+__global__ void cfg_linear_kernel(const half_t* __restrict__ eps2b, half_t* __restrict__ lat,
+                                  float* __restrict__ hist, long n, float g, float cx, float ce, float ch,
+                                  float hx, float he) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float eu = (float)eps2b[i], et = (float)eps2b[n + i];
+    const float e = (float)(half_t)(g * (et - eu) + eu);
+    const float x = (float)lat[i];
+    float out = cx * x + ce * e;
+    if (hist) {
+        out += ch * hist[i];
+        hist[i] = hx * x + he * e;
+    }
+    lat[i] = (half_t)out;
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -274,6 +293,12 @@ int launch_cfg_duplicate(const half_t* lat, half_t* out, long n, float scale, hi
 }
 int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx, float ce, hipStream_t s) {
     hipLaunchKernelGGL(cfg_ddim_kernel, grid1d(n), dim3(256), 0, s, eps2b, lat, n, g, cx, ce);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,
+                      float hx, float he, hipStream_t s) {
+    hipLaunchKernelGGL(cfg_linear_kernel, grid1d(n), dim3(256), 0, s, eps2b, lat, hist, n, g, cx, ce, ch, hx, he);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

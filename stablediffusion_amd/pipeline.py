@@ -244,11 +244,13 @@ class StableDiffusionUnifiedPipeline:
         # the UNet forward of every step.  One copy of the schedule to the host before the loop
         # removes those 50 bubbles; the values are the same.
         timesteps_host = [float(v) for v in timesteps.tolist()]
-        fused_step = self._fused_ddim_step_available(model, latents)
+        fused_step = self._fused_step_available(model, latents)
+        fused_hist = None
         for i, t in enumerate(timesteps_host):
             if fused_step:
-                latents = self._fused_cfg_ddim_iteration(model, latents, t, prompt_embeds, cross_attention_kwargs,
-                                                         added_cond_kwargs, guidance_scale)
+                latents, fused_hist = self._fused_cfg_iteration(model, latents, fused_hist, t, prompt_embeds,
+                                                                cross_attention_kwargs, added_cond_kwargs,
+                                                                guidance_scale)
                 continue
             latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
             latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
@@ -289,36 +291,41 @@ class StableDiffusionUnifiedPipeline:
         return images
 
     # ------------------------------------------------------------------------------------------
-    def _fused_ddim_step_available(self, model, latents) -> bool:
-        """CFG combine + DDIM update as ONE device kernel each side of the UNet:
-        the scheduler still computes its coefficients on the host (`DDIMScheduler.step_coefficients`),
-        the engine applies `x <- c_x x + c_eps (u + g (t - u))` (`sd_cfg_ddim_step`).  Only for the
-        plain txt2img / img2img loop with CFG on the HIP engine; everything else takes the generic path."""
+    def _fused_step_available(self, model, latents) -> bool:
+        """CFG combine + scheduler update as ONE device kernel each side of the UNet:
+        the scheduler still computes its coefficients on the host (`fused_plan`: DDIM, Euler, DPM++ 2M are
+        all affine in x, eps and the previous x0 prediction), the engine applies them
+        (`sd_cfg_duplicate`, `sd_cfg_linear_step`).  Only for the plain txt2img / img2img loop with CFG on
+        the HIP engine; everything else takes the generic path."""
         return (self.do_classifier_free_guidance and not self.is_inpaint
-                and isinstance(model.scheduler, _sched.DDIMScheduler)
+                and hasattr(model.scheduler, "fused_plan")
                 and hasattr(model.base, "_lib") and latents.is_cuda and latents.dtype == torch.float16)
 
-    def _fused_cfg_ddim_iteration(self, model, latents, t, prompt_embeds, cross_attention_kwargs, added_cond_kwargs,
-                                  guidance_scale):
+    def _fused_cfg_iteration(self, model, latents, hist, t, prompt_embeds, cross_attention_kwargs, added_cond_kwargs,
+                             guidance_scale):
         import ctypes as C
         lib = model.base._lib
+        plan = model.scheduler.fused_plan(t)
         latents = latents.contiguous()
         B = latents.shape[0]
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         lat2 = torch.empty((2 * B,) + tuple(latents.shape[1:]), device=latents.device, dtype=latents.dtype)
         rc = lib.sd_cfg_duplicate(C.c_void_p(latents.data_ptr()), C.c_void_p(lat2.data_ptr()),
-                                  latents[0].numel(), B, 1.0, st)
+                                  latents[0].numel(), B, plan.in_scale, st)
         if rc:
             raise RuntimeError(lib.sd_last_error().decode())
         noise_pred = model.base(lat2, t, prompt_embeds, cross_attention_kwargs=cross_attention_kwargs,
                                 added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
-        c_x, c_eps = model.scheduler.step_coefficients(t)
+        if plan.use_hist and hist is None:
+            hist = torch.zeros(latents.shape, device=latents.device, dtype=torch.float32)
         out = latents.clone()
-        rc = lib.sd_cfg_ddim_step(C.c_void_p(noise_pred.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),
-                                  float(guidance_scale), c_x, c_eps, st)
+        rc = lib.sd_cfg_linear_step(C.c_void_p(noise_pred.data_ptr()), C.c_void_p(out.data_ptr()),
+                                    C.c_void_p(hist.data_ptr()) if plan.use_hist else None, out.numel(),
+                                    float(guidance_scale), plan.c_x, plan.c_eps, plan.c_hist, plan.h_x, plan.h_eps, st)
         if rc:
             raise RuntimeError(lib.sd_last_error().decode())
-        return out
+        model.scheduler.fused_commit()
+        return out, hist
 
     def encode_prompt(self, prompt, prompt_2=None, negative_prompt=None, negative_prompt_2=None,
                       num_images_per_prompt=1, lora_scale=None, clip_skip=None):

@@ -17,6 +17,13 @@ import numpy as np
 import torch
 
 
+class FusedPlan(SimpleNamespace):
+    """One denoise step as the affine update the engine applies on the device (`sd_cfg_linear_step`):
+        x0 = h_x x + h_eps eps;   x <- c_x x + c_eps eps + c_hist hist;   hist <- x0
+    `in_scale` multiplies the UNet input (scale_model_input), `use_hist` says whether the scheduler
+    carries an x0 history.  Coefficients are float64 host values."""
+
+
 def _alphas_cumprod(T, beta_start, beta_end):
     betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
     return np.cumprod(1.0 - betas)
@@ -84,6 +91,13 @@ class DDIMScheduler(_Base):
         c_eps = (1 - a_prev) ** 0.5 - (a_prev * (1 - a_t) / a_t) ** 0.5
         return float(c_x), float(c_eps)
 
+    def fused_plan(self, timestep):
+        c_x, c_eps = self.step_coefficients(timestep)
+        return FusedPlan(in_scale=1.0, c_x=c_x, c_eps=c_eps, c_hist=0.0, h_x=0.0, h_eps=0.0, use_hist=False)
+
+    def fused_commit(self):
+        pass
+
     def step(self, model_output, timestep, sample, return_dict=False, **kw):
         c_x, c_eps = self.step_coefficients(timestep)
         prev = (c_x * sample.float() + c_eps * model_output.float()).to(sample.dtype)
@@ -111,11 +125,36 @@ class DPMSolverMultistepScheduler(_Base):
         self.timesteps = torch.from_numpy(ts).to(device)
         self._i = 0
         self._m_prev = None
+        self._fused_hist = False
 
     @staticmethod
     def _alpha_sigma(s):
         a = 1.0 / (s * s + 1.0) ** 0.5
         return a, s * a
+
+    def fused_plan(self, timestep=None):
+        """The arithmetic of `step` below, collected into coefficients of (x, eps, previous x0)."""
+        i, n = self._i, self.num_inference_steps
+        a0, sg0 = self._alpha_sigma(self.sigmas[i])
+        a_t, sg_t = self._alpha_sigma(self.sigmas[i + 1])
+        lam0 = np.log(a0) - np.log(sg0)
+        lam_t = np.log(a_t) - np.log(sg_t) if sg_t > 0 else np.inf
+        h = lam_t - lam0
+        em1 = float(np.exp(-h) - 1.0)
+        h_x, h_eps = 1.0 / a0, -sg0 / a0
+        first_order = i == 0 or i == n - 1 or not getattr(self, "_fused_hist", False)
+        b, c_hist = -a_t * em1, 0.0
+        if not first_order:
+            a1, sg1 = self._alpha_sigma(self.sigmas[i - 1])
+            r0 = (lam0 - (np.log(a1) - np.log(sg1))) / h
+            b = -a_t * em1 * (1.0 + 0.5 / r0)
+            c_hist = 0.5 * a_t * em1 / r0
+        return FusedPlan(in_scale=1.0, c_x=float(sg_t / sg0 + b * h_x), c_eps=float(b * h_eps), c_hist=float(c_hist),
+                         h_x=float(h_x), h_eps=float(h_eps), use_hist=True)
+
+    def fused_commit(self):
+        self._fused_hist = True
+        self._i += 1
 
     def step(self, model_output, timestep, sample, return_dict=False, **kw):
         i = self._i
@@ -163,6 +202,14 @@ class EulerDiscreteScheduler(_Base):
     def scale_model_input(self, sample, timestep=None):
         s = self.sigmas[self._i]
         return (sample.float() / float((s * s + 1) ** 0.5)).to(sample.dtype)
+
+    def fused_plan(self, timestep=None):
+        s, s_next = self.sigmas[self._i], self.sigmas[self._i + 1]
+        return FusedPlan(in_scale=float(1.0 / (s * s + 1) ** 0.5), c_x=1.0, c_eps=float(s_next - s), c_hist=0.0,
+                         h_x=0.0, h_eps=0.0, use_hist=False)
+
+    def fused_commit(self):
+        self._i += 1
 
     def step(self, model_output, timestep, sample, return_dict=False, **kw):
         s, s_next = self.sigmas[self._i], self.sigmas[self._i + 1]

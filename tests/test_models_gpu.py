@@ -207,6 +207,59 @@ def test_cfg_ddim_step_kernels(engine_lib):
     assert rel_l2(out, ref) < 1e-3
 
 
+def test_cfg_linear_step_kernel(engine_lib):
+    """sd_cfg_linear_step (DPM++ 2M form: history read and replaced) against the same formula in torch."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 4, 16, 16, generator=g).half().cuda()
+    eps = torch.randn(4, 4, 16, 16, generator=g).half().cuda()
+    hist = torch.randn(2, 4, 16, 16, generator=g).cuda()
+    cx, ce, ch, hx, he, gs = 0.93, -0.21, 0.07, 1.8, -1.5, 7.5
+    eu, et = eps.float().chunk(2)
+    e = (gs * (et - eu) + eu).half().float()
+    ref = cx * lat.float() + ce * e + ch * hist
+    ref_hist = hx * lat.float() + he * e
+    out, h2 = lat.clone(), hist.clone()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert engine_lib.sd_cfg_linear_step(C.c_void_p(eps.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(h2.data_ptr()),
+                                         lat.numel(), gs, cx, ce, ch, hx, he, st) == 0
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 1e-3 and rel_l2(h2, ref_hist) < 1e-5
+    out2 = lat.clone()                     # no history: DDIM / Euler form
+    assert engine_lib.sd_cfg_linear_step(C.c_void_p(eps.data_ptr()), C.c_void_p(out2.data_ptr()), None,
+                                         lat.numel(), gs, cx, ce, ch, hx, he, st) == 0
+    torch.cuda.synchronize()
+    assert rel_l2(out2, cx * lat.float() + ce * e) < 1e-3
+
+
+@pytest.mark.parametrize("sched", ["DDIM", "DPM++ 2M", "euler"])
+def test_fused_device_step_equals_host_scheduler_loop(engine_lib, sched):
+    """The loop with CFG + scheduler update fused on the device (sd_cfg_duplicate / sd_cfg_linear_step)
+    against the same engine driven through scheduler.scale_model_input / .step on the host."""
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = config.tiny_unet(), config.tiny_vae()
+    usd = _f16_round(weights.synth_state_dict(weights.unet_manifest(ucfg), 11))
+    vsd = _f16_round(weights.synth_state_dict(weights.vae_manifest(vcfg), 12))
+    model = SDModelWrapper(base=HipUNet2DConditionModel(ucfg).load_state_dict(usd),
+                           vae=HipAutoencoderKL(vcfg).load_state_dict(vsd), scheduler=DDIMScheduler(), device="cuda")
+    model.set_scheduler(sched)
+    g = torch.Generator().manual_seed(3)
+    pos = torch.randn(2, 7, ucfg.cross_attention_dim, generator=g).half().cuda()
+    neg = torch.randn(2, 7, ucfg.cross_attention_dim, generator=g).half().cuda()
+    lat0 = torch.randn(2, 4, 16, 16, generator=g).half().cuda()
+    kw = dict(prompt_embeds=pos, negative_prompt_embeds=neg, latents=lat0, num_inference_steps=6, guidance_scale=5.0,
+              height=128, width=128)
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda", output_type="latents")
+    fused = pipe(model, **kw)
+    assert pipe._fused_step_available(model, lat0)
+    host_pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda", output_type="latents")
+    host_pipe._fused_step_available = lambda *a: False
+    host = host_pipe(model, **kw)
+    assert torch.isfinite(fused.float()).all()
+    assert rel_l2(fused, host) < 3e-3
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size SD1.5 (BASELINE.json config C1: 256x256, 10-step DDIM, batch 1, CFG on)
 # ---------------------------------------------------------------------------------------------

@@ -94,6 +94,30 @@ def test_ddim_affine_coefficients():
         assert np.allclose(cx * x.numpy() + ce * e.numpy(), ref.step(e.numpy(), t, x.numpy()), atol=1e-12)
 
 
+@pytest.mark.parametrize("name,n", [("DDIM", 10), ("DPM++ 2M", 8), ("euler", 7)])
+def test_fused_plan_equals_step(name, n):
+    """The affine coefficients handed to sd_cfg_linear_step reproduce scheduler.step (fp32 emulation of
+    the kernel: x0 = h_x x + h_eps eps; x <- c_x x + c_eps eps + c_hist hist; hist <- x0)."""
+    cfg = schedulers.DDIMScheduler().config
+    a, b = schedulers.REGISTRY[name](cfg), schedulers.REGISTRY[name](cfg)
+    a.set_timesteps(n)
+    b.set_timesteps(n)
+    g = torch.Generator().manual_seed(n)
+    xa = torch.randn(2, 4, 8, 8, generator=g) * float(a.init_noise_sigma)
+    xb = xa.clone()
+    hist = torch.zeros_like(xb)
+    for t in a.timesteps.tolist():
+        eps = torch.randn(2, 4, 8, 8, generator=g)
+        plan = b.fused_plan(t)
+        assert rel_l2(plan.in_scale * xb, b.scale_model_input(xb, t)) < 1e-6
+        xa = a.step(eps, t, xa)[0]
+        x0 = plan.h_x * xb + plan.h_eps * eps
+        xb = plan.c_x * xb + plan.c_eps * eps + (plan.c_hist * hist if plan.use_hist else 0.0)
+        hist = x0
+        b.fused_commit()
+        assert rel_l2(xb, xa) < 1e-5, (name, t)
+
+
 def test_pipeline_host_logic_matches_oracle_loop(golden):
     """StableDiffusionUnifiedPipeline (product host code) driving oracle-backed doubles must equal
     the oracle's own loop: checks CFG order, scheduler wiring, un-scaling and decode call."""
