@@ -374,13 +374,18 @@ int g_force_splits = 0;
 // Variant ids (also used by the tuner in tests/tools): keep in sync with kIgemm2Names.
 //   0: 256x128 8 waves 3 stages   1: 128x128 4 waves 2 stages   2: 128x160 4 waves 2 stages
 //   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
+//   6 / 7: 256x128 / 256x160, 8 waves, staggered DMA issue
+//   8 / 9: 128x64 / 128x160 with a 3-deep ring: only pays on the small-M, deep-K shapes of the 8x8 and
+//          16x16 levels when their weights come cold from HBM (as they do inside a forward); with the
+//          weights cache-resident the 2-deep rings win everywhere (tools/tune_igemm.py, SD_BENCH_COLD_MB)
 // printf formats of the kernel names as rocprofv3 prints them (%s = the pointwise flag)
 static const char* kIgemm2Names[] = {
     "igemm2_kernel<256,128,4,2,3,%s,false,64>", "igemm2_kernel<128,128,2,2,2,%s,false,64>",
     "igemm2_kernel<128,160,2,2,2,%s,false,64>", "igemm2_kernel<128,64,2,2,2,%s,false,64>",
     "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
-    "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>"};
-constexpr int kNumVariants = 8;
+    "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
+    "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>"};
+constexpr int kNumVariants = 10;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -392,7 +397,8 @@ bool igemm2_supported(const IGemmParams& p) {
 }
 
 static void tile_dims(int v, int* bm, int* bn) {
-    static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160}};
+    static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
+                                               {128, 64}, {128, 160}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -464,6 +470,8 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 5: return launch_v2<256, 160, 4, 1, 3>(p, partial, sp, s);
         case 6: return launch_v2<256, 128, 4, 2, 3, true>(p, partial, sp, s);
         case 7: return launch_v2<256, 160, 4, 2, 3, true>(p, partial, sp, s);
+        case 8: return launch_v2<128, 64, 2, 2, 3>(p, partial, sp, s);
+        case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

@@ -72,7 +72,7 @@ def test_conv2d(engine_lib, case):
     assert rel_l2(got, ref) < 2e-3            # fp16 output rounding: ~5e-4 relative
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_conv2d_every_tile_variant(engine_lib, variant, splits):
     """Every LDS-DMA tile variant (and the split-K reduction) on a 3x3, a strided, an upsampled and a
