@@ -149,6 +149,11 @@ int sd_cfg_linear_step(const void* noise_pred_2b, void* latents, float* hist_f32
                        float guidance_scale, float c_x, float c_eps, float c_hist, float h_x, float h_eps,
                        void* stream);
 
+/* convert_pt_to_numpy (runpod-worker/handler_logic.py:21-29): decoded images [B,C,H,W] f16 in [-1,1] ->
+ * [B,H,W,C] uint8, with the reference's fp16 roundings and truncating cast (bit-exact with running
+ * the reference's op sequence on the same fp16 tensor).  C <= 4. */
+int sd_images_to_uint8(const void* images_nchw_f16, void* out_nhwc_u8, int B, int C, int H, int W, void* stream);
+
 /* -- per-kernel timing for bench.py's live roofline ----------------------------------------- */
 /* While enabled, every conv / norm / attention launch of the models is bracketed by HIP events on
  * the launch stream.  sd_prof_collect synchronises and returns one aggregate per kernel name:

@@ -84,6 +84,7 @@ SIGNATURES = {
     "sd_vae_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "sd_cfg_duplicate": (_I, [_P, _P, _I64, _I, _F, _P]),
     "sd_cfg_ddim_step": (_I, [_P, _P, _I64, _F, _F, _F, _P]),
+    "sd_images_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sd_cfg_linear_step": (_I, [_P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _P]),
     "sd_igemm_force": (_I, [_I, _I]),
     "sd_prof_enable": (_I, [_I]),

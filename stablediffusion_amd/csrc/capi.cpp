@@ -145,6 +145,14 @@ int sd_cfg_linear_step(const void* noise_pred_2b, void* latents, float* hist_f32
     return launch_cfg_linear(static_cast<const half_t*>(noise_pred_2b), static_cast<half_t*>(latents), hist_f32, (long)n,
                              guidance_scale, c_x, c_eps, c_hist, h_x, h_eps, static_cast<hipStream_t>(stream));
 }
+int sd_images_to_uint8(const void* images_nchw_f16, void* out_nhwc_u8, int B, int C, int H, int W, void* stream) {
+    if (!images_nchw_f16 || !out_nhwc_u8 || B < 0 || C < 1 || C > 4 || H < 1 || W < 1) {
+        set_error("sd_images_to_uint8: bad arguments (1..4 channels)");
+        return SD_ERR_INVALID;
+    }
+    return launch_image_to_uint8(static_cast<const half_t*>(images_nchw_f16), static_cast<unsigned char*>(out_nhwc_u8), B, C,
+                                 (long)H * W, static_cast<hipStream_t>(stream));
+}
 int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float guidance_scale, float c_x,
                      float c_eps, void* stream) {
     if (!noise_pred_2b || !latents) { set_error("null argument"); return SD_ERR_INVALID; }

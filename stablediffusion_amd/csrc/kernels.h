@@ -82,6 +82,7 @@ int launch_pointwise_nchw(const half_t* x, const half_t* w, const float* bias, h
 int launch_pack_conv(const half_t* w_oihw, half_t* wp, int O, int I, int KH, int KW, long Kpad,
                      hipStream_t s);
 int launch_cfg_duplicate(const half_t* lat, half_t* out, long n_total, float scale, hipStream_t s);
+int launch_image_to_uint8(const half_t* img, unsigned char* out, int B, int C, long HW, hipStream_t s);
 int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,
                       float hx, float he, hipStream_t s);
 int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx, float ce,

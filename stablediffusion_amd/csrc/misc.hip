@@ -222,6 +222,26 @@ __global__ void cfg_linear_kernel(const half_t* __restrict__ eps2b, half_t* __re
     lat[i] = (half_t)out;
 }
 
+// convert_pt_to_numpy (runpod-worker/handler_logic.py:21-29) on the device: the reference runs
+// (x / 2 + 0.5).clamp(0, 1), permute to HWC, * 255, .to(uint8) on the fp16 image tensor, i.e. every
+// step rounds to fp16 and the final cast truncates.  Same op order and roundings here, so the bytes
+// match the reference's bit for bit.  One thread per output pixel (C <= 4 channels).
+__global__ void image_to_uint8_kernel(const half_t* __restrict__ img, unsigned char* __restrict__ out, int C, long HW,
+                                      long total_px) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_px) return;
+    const long b = i / HW, px = i - b * HW;
+    const half_t* src = img + b * C * HW + px;
+    unsigned char* dst = out + i * C;
+    for (int c = 0; c < C; ++c) {
+        half_t v = src[(long)c * HW] * (half_t)0.5f;   // x / 2 (exact)
+        v = v + (half_t)0.5f;
+        v = v < (half_t)0.f ? (half_t)0.f : (v > (half_t)1.f ? (half_t)1.f : v);
+        v = v * (half_t)255.f;
+        dst[c] = (unsigned char)(int)(float)v;
+    }
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -299,6 +319,13 @@ int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx,
 int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,
                       float hx, float he, hipStream_t s) {
     hipLaunchKernelGGL(cfg_linear_kernel, grid1d(n), dim3(256), 0, s, eps2b, lat, hist, n, g, cx, ce, ch, hx, he);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_image_to_uint8(const half_t* img, unsigned char* out, int B, int C, long HW, hipStream_t s) {
+    const long total = (long)B * HW;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(image_to_uint8_kernel, grid1d(total), dim3(256), 0, s, img, out, C, HW, total);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

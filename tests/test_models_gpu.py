@@ -207,6 +207,23 @@ def test_cfg_ddim_step_kernels(engine_lib):
     assert rel_l2(out, ref) < 1e-3
 
 
+def test_images_to_uint8_matches_reference_op_sequence(engine_lib):
+    """sd_images_to_uint8 / convert_pt_to_numpy: bit-exact with the reference's own op sequence
+    (handler_logic.py:21-29) applied to the same fp16 tensor, including out-of-range and boundary values."""
+    from stablediffusion_amd.pipeline import convert_pt_to_numpy
+    g = torch.Generator().manual_seed(9)
+    img = (torch.randn(3, 3, 37, 53, generator=g) * 0.9).half()
+    img[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, 0.99951171875, -0.99951171875, 2.5, -3.0, 0.0039], dtype=torch.float16)
+    dev = img.cuda()
+    got = convert_pt_to_numpy(dev)
+    for idx in range(3):
+        ref = ((dev[idx] / 2 + 0.5).clamp(0, 1).permute(1, 2, 0) * 255).to(torch.uint8).cpu().numpy()
+        assert got[idx].shape == (37, 53, 3) and got[idx].dtype == ref.dtype
+        assert (got[idx] == ref).all()
+    cpu = convert_pt_to_numpy(img)          # host tensors: the op sequence itself
+    assert all((a == b).all() for a, b in zip(cpu, got))
+
+
 def test_cfg_linear_step_kernel(engine_lib):
     """sd_cfg_linear_step (DPM++ 2M form: history read and replaced) against the same formula in torch."""
     import ctypes as C
