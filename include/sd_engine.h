@@ -74,8 +74,23 @@ typedef struct sd_vae_config {
     int32_t norm_num_groups;
 } sd_vae_config;
 
+/* CLIP text encoder hyper-parameters (transformers CLIPTextConfig; the reference loads
+ * CLIPTextModel / CLIPTextModelWithProjection at models/stable_diffusion.py:124-152). */
+typedef struct sd_clip_config {
+    int32_t vocab_size;          /* 49408 */
+    int32_t hidden_size;         /* 768 (CLIP-L) / 1280 (OpenCLIP bigG) */
+    int32_t intermediate_size;   /* 3072 / 5120 */
+    int32_t num_layers;          /* 12 / 32 */
+    int32_t num_heads;           /* 12 / 20 */
+    int32_t max_positions;       /* 77 */
+    int32_t hidden_act;          /* 0 quick_gelu, 1 gelu (erf) */
+    int32_t projection_dim;      /* 0: CLIPTextModel; > 0: CLIPTextModelWithProjection.text_projection */
+    float layer_norm_eps;        /* 1e-5 */
+} sd_clip_config;
+
 typedef struct sd_unet sd_unet;
 typedef struct sd_vae sd_vae;
+typedef struct sd_clip sd_clip;
 
 /* -- library ------------------------------------------------------------------------------- */
 const char* sd_last_error(void);
@@ -130,6 +145,30 @@ int sd_vae_decode(sd_vae* v, const void* z, void* img, int B, int h, int w, void
  * img [B,3,H,W] f16 -> moments [B,8,H/8,W/8] f16 (mean | logvar); sampling stays host code. */
 int sd_vae_encode(sd_vae* v, const void* img, void* moments, int B, int H, int W, void* stream);
 int sd_vae_memory(const sd_vae* v, int64_t* weight_bytes, int64_t* workspace_bytes);
+
+/* -- CLIP text encoder: replaces SDModelWrapper.text_encoder / .text_encoder_2 as encode_prompt calls
+ *    them (sd_unified_pipeline.py:592-608).  Weight names are the
+ *    transformers state-dict keys ("text_model.embeddings.token_embedding.weight", ...,
+ *    "text_projection.weight"). ------------------------------------------------------------------ */
+int sd_clip_create(const sd_clip_config* cfg, sd_clip** out);
+int sd_clip_destroy(sd_clip* c);
+int sd_clip_num_weights(const sd_clip* c);
+int sd_clip_weight_info(const sd_clip* c, int index, const char** key, int64_t* shape4, int* ndim);
+int sd_clip_set_weight(sd_clip* c, const char* key, const void* data, const int64_t* shape, int ndim, int dtype);
+int sd_clip_finalize(sd_clip* c);
+/* text_encoder(input_ids, output_hidden_states=True): ids int32 [B,T] (device).  Outputs, each
+ * nullable, all f16 on the device:
+ *   hidden_states [num_layers+1, B, T, H]  (embeddings, then every layer's output; no final norm)
+ *   last_hidden   [B, T, H]                (final_layer_norm of the last one)
+ *   pooled        [B, H]                   (last_hidden at eos_index[b]; pooler_output)
+ *   text_embeds   [B, projection_dim]      (text_projection(pooled); needs projection_dim > 0)
+ * eos_index int32 [B] (device) is required for pooled / text_embeds: the host picks it the way
+ * transformers does (argmax of the ids, or first eos_token_id). */
+int sd_clip_forward(sd_clip* c, const int32_t* input_ids, const int32_t* eos_index, void* hidden_states,
+                    void* last_hidden, void* pooled, void* text_embeds, int B, int T, void* stream);
+/* text_encoder.text_model.final_layer_norm(x) for the clip_skip branch (sd_unified_pipeline.py:608). */
+int sd_clip_final_layer_norm(sd_clip* c, const void* x, void* y, int64_t rows, void* stream);
+int sd_clip_memory(const sd_clip* c, int64_t* weight_bytes, int64_t* workspace_bytes);
 
 /* -- denoise-step glue (sd_unified_pipeline.py:467-469, :484-489) ---------------------------- */
 /* latent_model_input = cat([latents]*2) * in_scale   (in_scale = 1 for DDIM / DPM++) */
@@ -199,6 +238,9 @@ int sd_op_layernorm(const void* x, const void* gamma, const void* beta, void* y,
 /* softmax(q k^T / sqrt(d)) v.  q [B,Tq,heads*d] (row stride ldq), k/v [B,Tk,heads*d], out like q. */
 int sd_op_attention(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk,
                     int heads, int d, int ldq, int ldk, int ldv, int ldo, void* stream);
+/* The same with a causal mask (key j > query i contributes nothing): CLIP text self-attention. */
+int sd_op_attention_causal(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk,
+                           int heads, int d, int ldq, int ldk, int ldv, int ldo, void* stream);
 
 #ifdef __cplusplus
 }

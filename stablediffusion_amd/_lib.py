@@ -50,6 +50,20 @@ class SdVAEConfig(C.Structure):
     ]
 
 
+class SdClipConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32),
+        ("hidden_size", C.c_int32),
+        ("intermediate_size", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("max_positions", C.c_int32),
+        ("hidden_act", C.c_int32),
+        ("projection_dim", C.c_int32),
+        ("layer_norm_eps", C.c_float),
+    ]
+
+
 class SdProfEntry(C.Structure):
     _fields_ = [("kernel", C.c_char * 64), ("flops", C.c_double), ("bytes", C.c_double),
                 ("ms", C.c_double), ("launches", C.c_int64)]
@@ -82,6 +96,16 @@ SIGNATURES = {
     "sd_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sd_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sd_vae_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "sd_clip_create": (_I, [C.POINTER(SdClipConfig), C.POINTER(_P)]),
+    "sd_clip_destroy": (_I, [_P]),
+    "sd_clip_num_weights": (_I, [_P]),
+    "sd_clip_weight_info": (_I, [_P, _I, C.POINTER(C.c_char_p), C.POINTER(_I64), C.POINTER(_I)]),
+    "sd_clip_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _I]),
+    "sd_clip_finalize": (_I, [_P]),
+    "sd_clip_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sd_clip_final_layer_norm": (_I, [_P, _P, _P, _I64, _P]),
+    "sd_clip_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
+    "sd_op_attention_causal": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sd_cfg_duplicate": (_I, [_P, _P, _I64, _I, _F, _P]),
     "sd_cfg_ddim_step": (_I, [_P, _P, _I64, _F, _F, _F, _P]),
     "sd_images_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -67,6 +67,46 @@ class VAEConfig:
         return asdict(self)
 
 
+@dataclass(frozen=True)
+class CLIPTextConfig:
+    """transformers CLIPTextConfig fields the engine needs (the reference loads the encoders at
+    /root/reference/models/stable_diffusion.py:124-152).  Defaults: CLIP ViT-L/14 text tower (SD1.5,
+    and `text_encoder` of SDXL)."""
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    max_position_embeddings: int = 77
+    hidden_act: str = "quick_gelu"
+    projection_dim: int = 0            # > 0: CLIPTextModelWithProjection
+    layer_norm_eps: float = 1e-5
+    eos_token_id: int = 2              # 2 = legacy configs: pooled token is ids.argmax (transformers modeling_clip)
+    bos_token_id: int = 1
+    pad_token_id: int = 1
+
+    def to_dict(self):
+        return asdict(self)
+
+    @classmethod
+    def from_hf(cls, hf, with_projection: bool = False):
+        return cls(vocab_size=hf.vocab_size, hidden_size=hf.hidden_size, intermediate_size=hf.intermediate_size,
+                   num_hidden_layers=hf.num_hidden_layers, num_attention_heads=hf.num_attention_heads,
+                   max_position_embeddings=hf.max_position_embeddings, hidden_act=hf.hidden_act,
+                   projection_dim=hf.projection_dim if with_projection else 0, layer_norm_eps=hf.layer_norm_eps,
+                   eos_token_id=hf.eos_token_id, bos_token_id=hf.bos_token_id, pad_token_id=hf.pad_token_id)
+
+
+def clip_l() -> CLIPTextConfig:
+    return CLIPTextConfig()
+
+
+def openclip_bigg() -> CLIPTextConfig:
+    """SDXL `text_encoder_2` (OpenCLIP ViT-bigG/14 text tower, with projection)."""
+    return CLIPTextConfig(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
+                          hidden_act="gelu", projection_dim=1280)
+
+
 def sd15_unet() -> UNetConfig:
     """SD1.5: 859 520 964 parameters (SURVEY.md §8c cross-check)."""
     return UNetConfig()

@@ -44,9 +44,9 @@ template <int D, int QT, int KT>
 __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                                                    const half_t* __restrict__ k,
                                                    const half_t* __restrict__ v,
-                                                   half_t* __restrict__ out, int Tq, int Tk,
+                                                   half_t* __restrict__ out, int Tq, int Tk_all,
                                                    int heads, long ldq, long ldk, long ldv,
-                                                   long ldo, float scale_log2e) {
+                                                   long ldo, float scale_log2e, int causal) {
     static_assert(KT == 64 || KT == 128, "keys per tile");
     constexpr int NSUB = KT / 16;                        // 16-key subtiles per tile
     constexpr int NKK = KT / 32;                         // 32-key k-steps of the PV product
@@ -76,8 +76,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     const int q0 = blockIdx.x * QB + wave * (16 * QT);
 
     const half_t* qb = q + (long)b * Tq * ldq + h * D;
-    const half_t* kb = k + (long)b * Tk * ldk + h * D;
-    const half_t* vb = v + (long)b * Tk * ldv + h * D;
+    // causal (CLIP text encoders): keys past the block's last query never contribute, so the key
+    // loop simply ends there; inside it key j > query i is masked like a ragged tail
+    int Tk = Tk_all;
+    if (causal && blockIdx.x * QB + QB < Tk) Tk = blockIdx.x * QB + QB;
+    const half_t* kb = k + (long)b * Tk_all * ldk + h * D;
+    const half_t* vb = v + (long)b * Tk_all * ldv + h * D;
 
     // ---- one-time LDS padding: K columns [D, DK) = 0 (the Q pad is zero too), V columns
     //      [D, VSTR) = 0 with a column of ones at D when the denominator rides on the PV MFMA ----
@@ -205,6 +209,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                     }
         }
 
+        if (causal && kt0 + KT - 1 > q0) {     // wave-uniform: some key of the tile may be ahead of a query
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int qi = q0 + t * 16 + fr;
+#pragma unroll
+                for (int ksub = 0; ksub < NSUB; ++ksub)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kt0 + ksub * 16 + fq * 4 + j > qi) s[ksub][t][j] = -INFINITY;
+            }
+        }
+
         // ---- online softmax: per query = per lane column ----
         unsigned pf[QT][NKK][4];               // P^T as packed fp16 pairs: [k-step of 32 keys][4 dwords]
         bool grow = false;
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 
 template <int D, int QT, int KT>
 int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq, int Tk,
-                int heads, long ldq, long ldk, long ldv, long ldo, hipStream_t s) {
+                int heads, long ldq, long ldk, long ldv, long ldo, int causal, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int DT = (D + 15) / 16;
     constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
@@ -319,7 +335,7 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, 
     }
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
     hipLaunchKernelGGL((attn_kernel<D, QT, KT>), dim3(cdiv(Tq, 64 * QT), B * heads), dim3(256), lds, s, q, k, v,
-                       out, Tq, Tk, heads, ldq, ldk, ldv, ldo, scale_log2e);
+                       out, Tq, Tk, heads, ldq, ldk, ldv, ldo, scale_log2e, causal);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -331,11 +347,11 @@ bool attention_supported(int d) {
 }
 
 int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq,
-                     int Tk, int heads, int d, long ldq, long ldk, long ldv, long ldo, hipStream_t s) {
+                     int Tk, int heads, int d, long ldq, long ldk, long ldv, long ldo, hipStream_t s, int causal) {
     if ((ldq | ldk | ldv | ldo) % 8 != 0) { set_error("attention: row strides must be multiples of 8"); return 1; }
     if (Tk <= 0 || Tq <= 0) return 0;
 #define SD_ATTN_CASE(DD, QQ, KK) \
-    case DD: return launch_attn<DD, QQ, KK>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, s)
+    case DD: return launch_attn<DD, QQ, KK>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, s)
     switch (d) {
         SD_ATTN_CASE(32, 2, 64);
         SD_ATTN_CASE(40, 4, 64);

@@ -10,6 +10,7 @@ using namespace sd;
 
 struct sd_unet { UNet impl; explicit sd_unet(const sd_unet_config& c) : impl(c) {} };
 struct sd_vae { VAE impl; explicit sd_vae(const sd_vae_config& c) : impl(c) {} };
+struct sd_clip { CLIP impl; explicit sd_clip(const sd_clip_config& c) : impl(c) {} };
 
 namespace {
 
@@ -130,6 +131,53 @@ int sd_vae_memory(const sd_vae* v, int64_t* weight_bytes, int64_t* workspace_byt
     if (!v) { set_error("null handle"); return SD_ERR_INVALID; }
     if (weight_bytes) *weight_bytes = v->impl.ws.packed_bytes();
     if (workspace_bytes) *workspace_bytes = (int64_t)v->impl.arena.capacity();
+    return SD_OK;
+}
+
+// ------------------------------------------------------------------------------------------- CLIP
+int sd_clip_create(const sd_clip_config* cfg, sd_clip** out) {
+    if (!out || !cfg) { set_error("null argument"); return SD_ERR_INVALID; }
+    const bool bad = cfg->vocab_size < 1 || cfg->num_layers < 1 || cfg->num_heads < 1 || cfg->max_positions < 1 ||
+                     cfg->hidden_size % 64 != 0 || cfg->intermediate_size % 64 != 0 || cfg->hidden_size > 2048 ||
+                     cfg->hidden_size % cfg->num_heads != 0 || !attention_supported(cfg->hidden_size / cfg->num_heads) ||
+                     (cfg->hidden_act != 0 && cfg->hidden_act != 1) || cfg->projection_dim < 0;
+    if (bad) { set_error("sd_clip_create: unsupported config (hidden / intermediate % 64, head dim, activation)"); return SD_ERR_UNSUPPORTED; }
+    *out = new (std::nothrow) sd_clip(*cfg);
+    if (!*out) { set_error("out of host memory"); return SD_ERR_INVALID; }
+    return SD_OK;
+}
+int sd_clip_destroy(sd_clip* c) { delete c; return SD_OK; }
+int sd_clip_num_weights(const sd_clip* c) { return c ? (int)c->impl.ws.order.size() : 0; }
+int sd_clip_weight_info(const sd_clip* c, int index, const char** key, int64_t* shape4, int* ndim) {
+    if (!c) { set_error("null handle"); return SD_ERR_INVALID; }
+    return weight_info(c->impl.ws, index, key, shape4, ndim);
+}
+int sd_clip_set_weight(sd_clip* c, const char* key, const void* data, const int64_t* shape, int ndim, int dtype) {
+    if (!c || !key || !data || !shape) { set_error("null argument"); return SD_ERR_INVALID; }
+    if (c->impl.finalized) { set_error("set_weight after finalize"); return SD_ERR_STATE; }
+    return c->impl.ws.set(key, data, shape, ndim, dtype);
+}
+int sd_clip_finalize(sd_clip* c) {
+    if (!c) { set_error("null handle"); return SD_ERR_INVALID; }
+    return c->impl.finalize();
+}
+int sd_clip_forward(sd_clip* c, const int32_t* input_ids, const int32_t* eos_index, void* hidden_states, void* last_hidden,
+                    void* pooled, void* text_embeds, int B, int T, void* stream) {
+    if (!c || !input_ids) { set_error("null argument"); return SD_ERR_INVALID; }
+    return c->impl.forward(input_ids, eos_index, static_cast<half_t*>(hidden_states), static_cast<half_t*>(last_hidden),
+                           static_cast<half_t*>(pooled), static_cast<half_t*>(text_embeds), B, T,
+                           static_cast<hipStream_t>(stream));
+}
+int sd_clip_final_layer_norm(sd_clip* c, const void* x, void* y, int64_t rows, void* stream) {
+    if (!c || !x || !y || rows < 0) { set_error("bad argument"); return SD_ERR_INVALID; }
+    if (rows == 0) return SD_OK;
+    return c->impl.final_layer_norm(static_cast<const half_t*>(x), static_cast<half_t*>(y), (long)rows,
+                                    static_cast<hipStream_t>(stream));
+}
+int sd_clip_memory(const sd_clip* c, int64_t* weight_bytes, int64_t* workspace_bytes) {
+    if (!c) { set_error("null handle"); return SD_ERR_INVALID; }
+    if (weight_bytes) *weight_bytes = c->impl.ws.packed_bytes();
+    if (workspace_bytes) *workspace_bytes = (int64_t)c->impl.arena.capacity();
     return SD_OK;
 }
 
@@ -349,6 +397,13 @@ int sd_op_attention(const void* q, const void* k, const void* v, void* out, int 
     return launch_attention(static_cast<const half_t*>(q), static_cast<const half_t*>(k),
                             static_cast<const half_t*>(v), static_cast<half_t*>(out), B, Tq, Tk, heads, d, ldq, ldk,
                             ldv, ldo, static_cast<hipStream_t>(stream));
+}
+
+int sd_op_attention_causal(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk, int heads, int d,
+                           int ldq, int ldk, int ldv, int ldo, void* stream) {
+    return launch_attention(static_cast<const half_t*>(q), static_cast<const half_t*>(k),
+                            static_cast<const half_t*>(v), static_cast<half_t*>(out), B, Tq, Tk, heads, d, ldq, ldk,
+                            ldv, ldo, static_cast<hipStream_t>(stream), 1);
 }
 
 }  // extern "C"

@@ -51,6 +51,10 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     const float erf_signed = __builtin_copysignf(erf_abs, x);
     return 0.5f * x * (1.0f + erf_signed);
 }
+// CLIP's quick_gelu: x * sigmoid(1.702 x)
+__device__ __forceinline__ float quick_gelu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
 // XCD-aware, bijective block-id remap (8 XCDs, round-robin dispatch): blocks that end up on one
 // XCD get a contiguous range of tile ids so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

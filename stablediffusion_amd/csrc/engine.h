@@ -107,9 +107,9 @@ int prof_collect(std::map<std::string, ProfAgg>* out);   // synchronises, aggreg
 // ---- op wrappers: skip the launch in dry mode, latch the first error ----
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride = 1, int up = 0,
              const float* rowadd = nullptr, int rowadd_ld = 0, const View* res = nullptr, int geglu = 0,
-             int pad = -1);
+             int pad = -1, int act = 0);
 void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu);
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps);
-void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d);
+void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal = 0);
 
 }  // namespace sd

@@ -249,6 +249,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
             if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + n0 + col);
             if (p.rowadd && n0 + col < p.Cout)
                 v += *reinterpret_cast<const f4*>(p.rowadd + (long)nimg * p.rowadd_ld + n0 + col);
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+            }
             h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
         }
@@ -393,7 +400,7 @@ bool igemm2_supported(const IGemmParams& p) {
     const long x_bytes = (long)p.N * p.H * p.W * p.ldx * 2;
     const long wrows = ((long)p.Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
     return p.K % BK == 0 && p.Cin % BK == 0 && (p.Cout % 8) == 0 && x_bytes < (1L << 31) &&
-           wrows * p.K * 2 < (1L << 31) && (!p.geglu || p.Cout % 128 == 0);
+           wrows * p.K * 2 < (1L << 31) && (!p.geglu || p.Cout % 128 == 0) && !(p.geglu && p.act);
 }
 
 static void tile_dims(int v, int* bm, int* bn) {
@@ -417,17 +424,24 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
         if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6) *variant = 1;
-        if (p.geglu) *splits = 1;
+        if (p.geglu || p.act) *splits = 1;
         return;
     }
     for (const TunedEntry& e : kTuned)
-        if (e.M == p.M && e.N == p.Cout && e.K == p.K && e.ks == p.KS && e.stride == p.stride && e.up == p.up &&
+        if (!p.act && e.M == p.M && e.N == p.Cout && e.K == p.K && e.ks == p.KS && e.stride == p.stride && e.up == p.up &&
             e.geglu == p.geglu) {
             *variant = e.variant; *splits = e.splits;
             return;
         }
     const int nk = p.K / BK;
     int v;
+    if (p.act) {                 // the activation lives in the fused epilogue only: never split K
+        v = (long)cdiv(p.M, 128) * cdiv(p.Cout, 64) >= 256 ? 3 : 4;
+        if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 128) >= 256) v = 1;
+        *variant = v;
+        *splits = 1;
+        return;
+    }
     if (p.geglu) v = (long)cdiv(p.M, 256) * cdiv(p.Cout, 128) >= 512 ? 0 : 1;
     else if (p.Cout % 160 == 0) v = 2;
     else v = 1;

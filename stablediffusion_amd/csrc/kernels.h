@@ -24,6 +24,8 @@ struct IGemmParams {
     int KS, stride, pad, up;
     int M, K;
     int geglu;              // 1: y[m, j] = hidden_j * gelu(gate_j), weights interleaved per 64
+    int act = 0;            // activation after bias, before residual (LDS-DMA kernels, no split-K):
+                            // 0 none, 1 quick_gelu x*sigmoid(1.702x) (CLIP-L MLP), 2 exact-erf gelu (OpenCLIP MLP)
 };
 int launch_igemm(const IGemmParams& p, hipStream_t s);
 const char* igemm_variant(const IGemmParams& p);   // name of the tile variant launch_igemm picks
@@ -53,7 +55,7 @@ int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float*
 // ---------------------------------------------------------------------------------------------
 int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* out,
                      int B, int Tq, int Tk, int heads, int d,
-                     long ldq, long ldk, long ldv, long ldo, hipStream_t s);
+                     long ldq, long ldk, long ldv, long ldo, hipStream_t s, int causal = 0);
 bool attention_supported(int d);
 
 // ---------------------------------------------------------------------------------------------
@@ -82,6 +84,12 @@ int launch_pointwise_nchw(const half_t* x, const half_t* w, const float* bias, h
 int launch_pack_conv(const half_t* w_oihw, half_t* wp, int O, int I, int KH, int KW, long Kpad,
                      hipStream_t s);
 int launch_cfg_duplicate(const half_t* lat, half_t* out, long n_total, float scale, hipStream_t s);
+// CLIP text embeddings: out[b, t, :] = token_table[ids[b, t], :] + position_table[t, :]  (ids clamped to the table)
+int launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* out, int B, int T, int H, int vocab,
+                      hipStream_t s);
+// out[b, :] = x[b * T + idx[b], :] as f16 (out16) and / or f32 (out32); idx clamped to [0, T)
+int launch_gather_rows(const half_t* x, long ldx, const int* idx, half_t* out16, float* out32, int B, int T, int H,
+                       hipStream_t s);
 int launch_image_to_uint8(const half_t* img, unsigned char* out, int B, int C, long HW, hipStream_t s);
 int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,
                       float hx, float he, hipStream_t s);

@@ -242,6 +242,36 @@ __global__ void image_to_uint8_kernel(const half_t* __restrict__ img, unsigned c
     }
 }
 
+// CLIPTextEmbeddings (transformers modeling_clip.py): token + learned position embedding.
+__global__ void clip_embed_kernel(const int* __restrict__ ids, const half_t* __restrict__ tok,
+                                  const half_t* __restrict__ pos, half_t* __restrict__ out, long rows, int T, int H8,
+                                  int vocab) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * H8) return;
+    const long r = i / H8;
+    const int c = (int)(i - r * H8) * 8;
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const int t = (int)(r % T);
+    const h8 a = *reinterpret_cast<const h8*>(tok + (long)id * H8 * 8 + c);
+    const h8 b = *reinterpret_cast<const h8*>(pos + (long)t * H8 * 8 + c);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+    *reinterpret_cast<h8*>(out + r * H8 * 8 + c) = o;
+}
+__global__ void gather_rows_kernel(const half_t* __restrict__ x, long ldx, const int* __restrict__ idx,
+                                   half_t* __restrict__ out16, float* __restrict__ out32, int B, int T, int H) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * H) return;
+    const int b = (int)(i / H), c = (int)(i - (long)b * H);
+    int t = idx[b];
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    const half_t v = x[((long)b * T + t) * ldx + c];
+    if (out16) out16[i] = v;
+    if (out32) out32[i] = (float)v;
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -319,6 +349,20 @@ int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx,
 int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,
                       float hx, float he, hipStream_t s) {
     hipLaunchKernelGGL(cfg_linear_kernel, grid1d(n), dim3(256), 0, s, eps2b, lat, hist, n, g, cx, ce, ch, hx, he);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* out, int B, int T, int H, int vocab,
+                      hipStream_t s) {
+    if (H % 8 != 0) { set_error("clip_embed: hidden size must be a multiple of 8"); return 1; }
+    const long n = (long)B * T * (H / 8);
+    hipLaunchKernelGGL(clip_embed_kernel, grid1d(n), dim3(256), 0, s, ids, tok, pos, out, (long)B * T, T, H / 8, vocab);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_gather_rows(const half_t* x, long ldx, const int* idx, half_t* out16, float* out32, int B, int T, int H,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, grid1d((long)B * H), dim3(256), 0, s, x, ldx, idx, out16, out32, B, T, H);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -121,4 +121,33 @@ struct VAE {
     int run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W);
 };
 
+// CLIP text encoder (transformers CLIPTextModel / CLIPTextModelWithProjection): the text side of
+// encode_prompt, /root/reference/pipelines/sd_unified_pipeline.py:583-608.
+struct ClipLayer {
+    NormW ln1, ln2;
+    ConvW qkv, out, fc1, fc2;
+};
+struct CLIP {
+    explicit CLIP(const sd_clip_config& c);
+    int finalize();
+    int forward(const int* ids, const int* eos_index, half_t* hidden_states, half_t* last_hidden, half_t* pooled,
+                half_t* text_embeds, int B, int T, hipStream_t stream);
+    int final_layer_norm(const half_t* x, half_t* y, long rows, hipStream_t stream);
+
+    sd_clip_config cfg;
+    WeightStore ws;
+    Arena arena;
+    bool finalized = false;
+    long planned_key = -1;
+    half_t* tok = nullptr;      // [vocab][H]
+    half_t* pos = nullptr;      // [max_positions][H]
+    half_t* proj = nullptr;     // [projection_dim][H], no bias
+    std::vector<ClipLayer> layers;
+    NormW final_ln;
+
+  private:
+    int run(Ctx& c, const int* ids, const int* eos_index, half_t* hidden_states, half_t* last_hidden, half_t* pooled,
+            half_t* text_embeds, int B, int T);
+};
+
 }  // namespace sd

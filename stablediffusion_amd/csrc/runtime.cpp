@@ -276,7 +276,7 @@ int prof_collect(std::map<std::string, ProfAgg>* out) {
 
 // -------------------------------------------------------------------------------------------- ops
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride, int up,
-             const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad) {
+             const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad, int act) {
     IGemmParams p;
     p.x = x.p; p.ldx = x.ld;
     p.w = w.w; p.bias = w.bias;
@@ -300,7 +300,9 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
     p.M = N * p.OH * p.OW;
     p.K = (int)w.K;
     p.geglu = geglu;
+    p.act = act;
     const bool v2 = igemm2_supported(p);
+    if (act && !v2) { set_error("op_conv: activation epilogue needs the LDS-DMA kernel (Cin % 64, Cout % 8)"); c.err = 1; return; }
     float* partial = nullptr;
     if (v2) {
         const long pf = igemm2_partial_floats(p);
@@ -345,7 +347,7 @@ void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps) 
     prof_close(c.stream);
 }
 
-void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d) {
+void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal) {
     if (c.dry || c.err) return;
     if (prof_enabled()) {
         static thread_local char name[32];
@@ -353,7 +355,7 @@ void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int T
         prof_open(c.stream, name, 4.0 * B * heads * (double)Tq * Tk * d,
                   2.0 * B * heads * d * (2.0 * Tq + 2.0 * Tk));
     }
-    c.err = launch_attention(q.p, k.p, v.p, out.p, B, Tq, Tk, heads, d, q.ld, k.ld, v.ld, out.ld, c.stream);
+    c.err = launch_attention(q.p, k.p, v.p, out.p, B, Tq, Tk, heads, d, q.ld, k.ld, v.ld, out.ld, c.stream, causal);
     prof_close(c.stream);
 }
 

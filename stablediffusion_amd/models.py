@@ -292,3 +292,146 @@ class HipAutoencoderKL:
                 self._h = None
         except Exception:
             pass
+
+
+class _ClipOutput(tuple):
+    """Indexable like transformers' ModelOutput (positional order of the non-None fields) with the
+    same attribute names: encode_prompt uses `out[0]`, `out[-1][-(k+1)]` and `out.hidden_states[-2]`
+    (/root/reference/pipelines/sd_unified_pipeline.py:596-608)."""
+
+    def __new__(cls, names, values):
+        o = super().__new__(cls, values)
+        o._names = tuple(names)
+        return o
+
+    def __getattr__(self, name):
+        names = object.__getattribute__(self, "_names")
+        if name in names:
+            return self[names.index(name)]
+        if name in ("last_hidden_state", "pooler_output", "text_embeds", "hidden_states", "attentions"):
+            return None
+        raise AttributeError(name)
+
+    def keys(self):
+        return list(self._names)
+
+
+class HipCLIPTextModel:
+    """gfx950 engine behind the call surface the reference uses on `SDModelWrapper.text_encoder` /
+    `.text_encoder_2` (transformers CLIPTextModel / CLIPTextModelWithProjection): `__call__(input_ids,
+    output_hidden_states=True)`, `.text_model.final_layer_norm`, `.config`, `.dtype`, `.to`.
+    `projection_dim > 0` in the config selects the WithProjection flavour (`out[0]` = text_embeds)."""
+
+    def __init__(self, config, device: str = "cuda"):
+        from .config import CLIPTextConfig
+        if not isinstance(config, CLIPTextConfig):
+            raise TypeError("config must be a stablediffusion_amd.config.CLIPTextConfig (see CLIPTextConfig.from_hf)")
+        acts = {"quick_gelu": 0, "gelu": 1}
+        if config.hidden_act not in acts:
+            raise _lib.EngineError(f"unsupported CLIP activation {config.hidden_act!r}")
+        self._lib = _lib.load()
+        self.cfg = config
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        c = _lib.SdClipConfig()
+        c.vocab_size = config.vocab_size
+        c.hidden_size = config.hidden_size
+        c.intermediate_size = config.intermediate_size
+        c.num_layers = config.num_hidden_layers
+        c.num_heads = config.num_attention_heads
+        c.max_positions = config.max_position_embeddings
+        c.hidden_act = acts[config.hidden_act]
+        c.projection_dim = config.projection_dim
+        c.layer_norm_eps = config.layer_norm_eps
+        self._h = C.c_void_p()
+        _lib.check(self._lib.sd_clip_create(C.byref(c), C.byref(self._h)), "sd_clip_create")
+        self.config = _Config(**config.to_dict())
+        self._finalized = False
+        self.text_model = SimpleNamespace(final_layer_norm=self._final_layer_norm)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.sd_clip_destroy(self._h)
+        except Exception:
+            pass
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """transformers state-dict keys; the `text_model.` prefix is optional (transformers >= 5 drops it
+        for CLIPTextModel), buffers such as `position_ids` are ignored."""
+        _lib.require_gpu()
+        sd = {}
+        for k, v in state_dict.items():
+            if k.endswith("position_ids"):
+                continue
+            if not k.startswith("text_model.") and not k.startswith("text_projection."):
+                k = "text_model." + k
+            if k.startswith("text_projection.") and self.cfg.projection_dim == 0:
+                continue
+            sd[k] = v
+        with torch.cuda.device(self.device):
+            _load_weights(self._lib, self._h, "clip", sd, strict)
+            _lib.check(self._lib.sd_clip_finalize(self._h), "sd_clip_finalize")
+        self._finalized = True
+        return self
+
+    def memory(self):
+        w, s = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.sd_clip_memory(self._h, C.byref(w), C.byref(s)), "sd_clip_memory")
+        return w.value, s.value
+
+    def to(self, device=None, dtype=None):
+        if device is not None and not isinstance(device, torch.dtype) and torch.device(device).type != "cuda":
+            raise _lib.EngineError("HipCLIPTextModel lives on the HIP device only")
+        return self
+
+    def eval(self):
+        return self
+
+    def _final_layer_norm(self, x: torch.Tensor) -> torch.Tensor:
+        x = _as_f16(x, self.device)
+        y = torch.empty_like(x)
+        rows = x.numel() // self.cfg.hidden_size
+        with torch.cuda.device(self.device):
+            rc = self._lib.sd_clip_final_layer_norm(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), rows,
+                                                    C.c_void_p(_stream_ptr()))
+        _lib.check(rc, "sd_clip_final_layer_norm")
+        return y
+
+    def _eos_index(self, ids: torch.Tensor) -> torch.Tensor:
+        # transformers modeling_clip: legacy configs (eos_token_id == 2) pool at ids.argmax, newer ones
+        # at the first eos_token_id
+        if self.cfg.eos_token_id == 2:
+            return ids.argmax(dim=-1).to(torch.int32)
+        return (ids == self.cfg.eos_token_id).int().argmax(dim=-1).to(torch.int32)
+
+    def __call__(self, input_ids, attention_mask=None, position_ids=None, output_attentions=None,
+                 output_hidden_states=None, return_dict=True, **unused):
+        if not self._finalized:
+            raise _lib.EngineError("weights not loaded")
+        if attention_mask is not None or position_ids is not None or output_attentions:
+            raise NotImplementedError("HipCLIPTextModel: attention_mask / position_ids / output_attentions are not "
+                                      "used by the reference's encode_prompt and not supported")
+        ids = input_ids.to(self.device)
+        B, T = ids.shape
+        H, L, P = self.cfg.hidden_size, self.cfg.num_hidden_layers, self.cfg.projection_dim
+        ids32 = ids.to(torch.int32).contiguous()
+        eos = self._eos_index(ids).contiguous()
+        f16 = dict(device=self.device, dtype=torch.float16)
+        hs = torch.empty((L + 1, B, T, H), **f16) if output_hidden_states else None
+        last = torch.empty((B, T, H), **f16)
+        pooled = torch.empty((B, H), **f16)
+        emb = torch.empty((B, P), **f16) if P > 0 else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(self.device):
+            rc = self._lib.sd_clip_forward(self._h, ptr(ids32), ptr(eos), ptr(hs), ptr(last), ptr(pooled), ptr(emb), B, T,
+                                           C.c_void_p(_stream_ptr()))
+        _lib.check(rc, "sd_clip_forward")
+        names, vals = [], []
+        if P > 0:       # CLIPTextModelOutput: text_embeds, last_hidden_state, hidden_states
+            names += ["text_embeds", "last_hidden_state"]; vals += [emb, last]
+        else:           # BaseModelOutputWithPooling: last_hidden_state, pooler_output, hidden_states
+            names += ["last_hidden_state", "pooler_output"]; vals += [last, pooled]
+        if hs is not None:
+            names.append("hidden_states"); vals.append(tuple(hs[i] for i in range(L + 1)))
+        return _ClipOutput(names, vals)
