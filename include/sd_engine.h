@@ -238,9 +238,12 @@ int sd_op_layernorm(const void* x, const void* gamma, const void* beta, void* y,
 /* softmax(q k^T / sqrt(d)) v.  q [B,Tq,heads*d] (row stride ldq), k/v [B,Tk,heads*d], out like q. */
 int sd_op_attention(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk,
                     int heads, int d, int ldq, int ldk, int ldv, int ldo, void* stream);
-/* The same with a causal mask (key j > query i contributes nothing): CLIP text self-attention. */
-int sd_op_attention_causal(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk,
-                           int heads, int d, int ldq, int ldk, int ldv, int ldo, void* stream);
+/* The same with options.  causal = 1: key j > query i contributes nothing (CLIP text self-attention).
+ * prescaled = 1: q already carries log2(e)/sqrt(d) (the UNet folds it into its query projections),
+ * the kernel then skips its per-score scaling. */
+int sd_op_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk,
+                       int heads, int d, int ldq, int ldk, int ldv, int ldo, int causal, int prescaled,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,7 +105,7 @@ SIGNATURES = {
     "sd_clip_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sd_clip_final_layer_norm": (_I, [_P, _P, _P, _I64, _P]),
     "sd_clip_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
-    "sd_op_attention_causal": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sd_op_attention_ex": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sd_cfg_duplicate": (_I, [_P, _P, _I64, _I, _F, _P]),
     "sd_cfg_ddim_step": (_I, [_P, _P, _I64, _F, _F, _F, _P]),
     "sd_images_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned pack_rtz(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-template <int D, int QT, int KT>
+template <int D, int QT, int KT, bool PRESC>
 __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                                                    const half_t* __restrict__ k,
                                                    const half_t* __restrict__ v,
@@ -123,7 +123,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
         for (int t = 0; t < QT; ++t) o[i][t] = f4{0.f, 0.f, 0.f, 0.f};
     float mrun[QT], lrun[QT];     // running max in the scaled log2 domain; partial row sums (!ONES)
 #pragma unroll
-    for (int t = 0; t < QT; ++t) { mrun[t] = -INFINITY; lrun[t] = 0.f; }
+    for (int t = 0; t < QT; ++t) { mrun[t] = PRESC ? 0.f : -INFINITY; lrun[t] = 0.f; }
+    // PRESC (the model pre-multiplies the query projection by log2(e)/sqrt(d)): the scores come out
+    // of the QK^T MFMA in the log2 domain already, and the running reference `mrun` is subtracted by
+    // starting that MFMA's accumulators at -mrun instead of 0 -- the per-score FMA of the general
+    // path disappears (15 % of this VALU-issue-bound loop at d = 40).
+    f4 negm[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) negm[t] = f4{0.f, 0.f, 0.f, 0.f};
 
     // staging registers (next tile)
     h8 kreg[PREFETCH ? LIT : 1], vreg[PREFETCH ? LIT : 1];
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 #pragma unroll
         for (int ksub = 0; ksub < NSUB; ++ksub)
 #pragma unroll
-            for (int t = 0; t < QT; ++t) s[ksub][t] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < QT; ++t) s[ksub][t] = PRESC ? negm[t] : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -223,47 +230,97 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 
         // ---- online softmax: per query = per lane column ----
         unsigned pf[QT][NKK][4];               // P^T as packed fp16 pairs: [k-step of 32 keys][4 dwords]
-        bool grow = false;
-        float mx[QT];
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int ksub = 0; ksub < NSUB; ++ksub)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) m = fmaxf(m, s[ksub][t][j]);
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            mx[t] = m * scale_log2e;
-            grow |= mx[t] > mrun[t] + kRescaleThreshold;
-        }
-        if (__any(grow)) {                     // wave-uniform: rescale everything kept at the old max
+        if constexpr (PRESC) {
+            // s already holds (score - mrun) in log2 units.  The reference only has to keep exp2 inside
+            // fp16: it moves (wave-uniformly) when some score exceeds it by 2^8, and on the first
+            // tile, where it is set to the tile's own row maximum.
+            float mx[QT];
+            bool grow = kt0 == 0;
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                const float mnew = fmaxf(mrun[t], mx[t]);
-                const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
-                mrun[t] = mnew;
-                lrun[t] *= alpha;
+                float m = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < DT; ++i) o[i][t] *= alpha;
+                for (int ksub = 0; ksub < NSUB; ++ksub)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m = fmaxf(m, s[ksub][t][j]);
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                mx[t] = m;
+                grow |= m > kRescaleThreshold;
             }
-        }
+            if (__any(grow)) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const float nm = -mrun[t];
-            float psum = 0.f;
+                for (int t = 0; t < QT; ++t) {
+                    const float delta = kt0 == 0 ? mx[t] : fmaxf(mx[t], 0.f);
+                    const float alpha = kt0 == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);   // o, l are 0 on tile 0
+                    mrun[t] += delta;
+                    negm[t] = f4{-mrun[t], -mrun[t], -mrun[t], -mrun[t]};
 #pragma unroll
-            for (int ksub = 0; ksub < NSUB; ++ksub) {
-                float p[4];
+                    for (int i = 0; i < DT; ++i) o[i][t] *= alpha;
+                    lrun[t] *= alpha;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ksub][t][j], scale_log2e, nm));
-                    if (!ONES) psum += p[j];
+                    for (int ksub = 0; ksub < NSUB; ++ksub) s[ksub][t] -= delta;
                 }
-                pf[t][ksub >> 1][(ksub & 1) * 2] = pack_rtz(p[0], p[1]);
-                pf[t][ksub >> 1][(ksub & 1) * 2 + 1] = pack_rtz(p[2], p[3]);
             }
-            if (!ONES) lrun[t] += psum;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float psum = 0.f;
+#pragma unroll
+                for (int ksub = 0; ksub < NSUB; ++ksub) {
+                    float p[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        p[j] = __builtin_amdgcn_exp2f(s[ksub][t][j]);
+                        if (!ONES) psum += p[j];
+                    }
+                    pf[t][ksub >> 1][(ksub & 1) * 2] = pack_rtz(p[0], p[1]);
+                    pf[t][ksub >> 1][(ksub & 1) * 2 + 1] = pack_rtz(p[2], p[3]);
+                }
+                if (!ONES) lrun[t] += psum;
+            }
+        } else {
+            bool grow = false;
+            float mx[QT];
+    #pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float m = -INFINITY;
+    #pragma unroll
+                for (int ksub = 0; ksub < NSUB; ++ksub)
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) m = fmaxf(m, s[ksub][t][j]);
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                mx[t] = m * scale_log2e;
+                grow |= mx[t] > mrun[t] + kRescaleThreshold;
+            }
+            if (__any(grow)) {                     // wave-uniform: rescale everything kept at the old max
+    #pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const float mnew = fmaxf(mrun[t], mx[t]);
+                    const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
+                    mrun[t] = mnew;
+                    lrun[t] *= alpha;
+    #pragma unroll
+                    for (int i = 0; i < DT; ++i) o[i][t] *= alpha;
+                }
+            }
+    #pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float nm = -mrun[t];
+                float psum = 0.f;
+    #pragma unroll
+                for (int ksub = 0; ksub < NSUB; ++ksub) {
+                    float p[4];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ksub][t][j], scale_log2e, nm));
+                        if (!ONES) psum += p[j];
+                    }
+                    pf[t][ksub >> 1][(ksub & 1) * 2] = pack_rtz(p[0], p[1]);
+                    pf[t][ksub >> 1][(ksub & 1) * 2 + 1] = pack_rtz(p[2], p[3]);
+                }
+                if (!ONES) lrun[t] += psum;
+            }
         }
 
         // ---- O^T += V^T P^T ----
@@ -321,20 +378,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     }
 }
 
-template <int D, int QT, int KT>
+template <int D, int QT, int KT, bool PRESC>
 int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq, int Tk,
-                int heads, long ldq, long ldk, long ldv, long ldo, int causal, hipStream_t s) {
+                int heads, long ldq, long ldk, long ldv, long ldo, int causal, bool q_has_scale, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int DT = (D + 15) / 16;
     constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT>),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT, PRESC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const float scale_log2e = 1.4426950408889634f / sqrtf((float)D);
-    hipLaunchKernelGGL((attn_kernel<D, QT, KT>), dim3(cdiv(Tq, 64 * QT), B * heads), dim3(256), lds, s, q, k, v,
+    // q_has_scale with the general kernel: the scores only need the running-max subtraction
+    const float scale_log2e = q_has_scale ? 1.0f : 1.4426950408889634f / sqrtf((float)D);
+    hipLaunchKernelGGL((attn_kernel<D, QT, KT, PRESC>), dim3(cdiv(Tq, 64 * QT), B * heads), dim3(256), lds, s, q, k, v,
                        out, Tq, Tk, heads, ldq, ldk, ldv, ldo, scale_log2e, causal);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
@@ -347,19 +405,25 @@ bool attention_supported(int d) {
 }
 
 int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq,
-                     int Tk, int heads, int d, long ldq, long ldk, long ldv, long ldo, hipStream_t s, int causal) {
+                     int Tk, int heads, int d, long ldq, long ldk, long ldv, long ldo, hipStream_t s, int causal,
+                     int prescaled) {
     if ((ldq | ldk | ldv | ldo) % 8 != 0) { set_error("attention: row strides must be multiples of 8"); return 1; }
     if (Tk <= 0 || Tq <= 0) return 0;
-#define SD_ATTN_CASE(DD, QQ, KK) \
-    case DD: return launch_attn<DD, QQ, KK>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, s)
+    // FAST: whether the accumulator-start form pays for this head dim (measured: -12 % at d = 40,
+    // -7 % at d = 80, +1.5 % at d = 64 where the loop is less VALU-bound); otherwise pre-scaled
+    // queries run the general kernel with a unit scale
+#define SD_ATTN_CASE(DD, QQ, KK, FAST) \
+    case DD: return (prescaled && FAST) \
+        ? launch_attn<DD, QQ, KK, FAST>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, true, s) \
+        : launch_attn<DD, QQ, KK, false>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, prescaled != 0, s)
     switch (d) {
-        SD_ATTN_CASE(32, 2, 64);
-        SD_ATTN_CASE(40, 4, 64);
-        SD_ATTN_CASE(64, 2, 64);
-        SD_ATTN_CASE(80, 2, 64);
-        SD_ATTN_CASE(128, 2, 64);
-        SD_ATTN_CASE(160, 2, 64);
-        SD_ATTN_CASE(512, 1, 64);
+        SD_ATTN_CASE(32, 2, 64, true);
+        SD_ATTN_CASE(40, 4, 64, true);
+        SD_ATTN_CASE(64, 2, 64, false);
+        SD_ATTN_CASE(80, 2, 64, true);
+        SD_ATTN_CASE(128, 2, 64, false);
+        SD_ATTN_CASE(160, 2, 64, true);
+        SD_ATTN_CASE(512, 1, 64, false);
         default:
             set_error("attention: unsupported head dim " + std::to_string(d));
             return 4;

@@ -399,11 +399,11 @@ int sd_op_attention(const void* q, const void* k, const void* v, void* out, int 
                             ldv, ldo, static_cast<hipStream_t>(stream));
 }
 
-int sd_op_attention_causal(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk, int heads, int d,
-                           int ldq, int ldk, int ldv, int ldo, void* stream) {
+int sd_op_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int Tq, int Tk, int heads, int d,
+                       int ldq, int ldk, int ldv, int ldo, int causal, int prescaled, void* stream) {
     return launch_attention(static_cast<const half_t*>(q), static_cast<const half_t*>(k),
                             static_cast<const half_t*>(v), static_cast<half_t*>(out), B, Tq, Tk, heads, d, ldq, ldk,
-                            ldv, ldo, static_cast<hipStream_t>(stream), 1);
+                            ldv, ldo, static_cast<hipStream_t>(stream), causal, prescaled);
 }
 
 }  // extern "C"

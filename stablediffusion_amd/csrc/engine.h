@@ -110,6 +110,7 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
              int pad = -1, int act = 0);
 void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu);
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps);
-void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal = 0);
+void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal = 0,
+                  int prescaled = 0);
 
 }  // namespace sd

@@ -55,7 +55,9 @@ int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float*
 // ---------------------------------------------------------------------------------------------
 int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* out,
                      int B, int Tq, int Tk, int heads, int d,
-                     long ldq, long ldk, long ldv, long ldo, hipStream_t s, int causal = 0);
+                     long ldq, long ldk, long ldv, long ldo, hipStream_t s, int causal = 0, int prescaled = 0);
+// prescaled = 1: q already carries log2(e)/sqrt(d) (the UNet folds it into its query projections at
+// pack time, launch_scale_f16), which lets the kernel drop its per-score scale-and-subtract FMA.
 bool attention_supported(int d);
 
 // ---------------------------------------------------------------------------------------------
@@ -90,6 +92,7 @@ int launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half
 // out[b, :] = x[b * T + idx[b], :] as f16 (out16) and / or f32 (out32); idx clamped to [0, T)
 int launch_gather_rows(const half_t* x, long ldx, const int* idx, half_t* out16, float* out32, int B, int T, int H,
                        hipStream_t s);
+int launch_scale_f16(half_t* x, long n, float scale, hipStream_t s);     // x *= scale (fp32 multiply, one rounding)
 int launch_image_to_uint8(const half_t* img, unsigned char* out, int B, int C, long HW, hipStream_t s);
 int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,
                       float hx, float he, hipStream_t s);

@@ -272,6 +272,11 @@ __global__ void gather_rows_kernel(const half_t* __restrict__ x, long ldx, const
     if (out32) out32[i] = (float)v;
 }
 
+__global__ void scale_f16_kernel(half_t* __restrict__ x, long n, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = (half_t)((float)x[i] * scale);
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -363,6 +368,12 @@ int launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half
 int launch_gather_rows(const half_t* x, long ldx, const int* idx, half_t* out16, float* out32, int B, int T, int H,
                        hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, grid1d((long)B * H), dim3(256), 0, s, x, ldx, idx, out16, out32, B, T, H);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_scale_f16(half_t* x, long n, float scale, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scale_f16_kernel, grid1d(n), dim3(256), 0, s, x, n, scale);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -347,7 +347,8 @@ void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps) 
     prof_close(c.stream);
 }
 
-void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal) {
+void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal,
+                  int prescaled) {
     if (c.dry || c.err) return;
     if (prof_enabled()) {
         static thread_local char name[32];
@@ -355,7 +356,7 @@ void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int T
         prof_open(c.stream, name, 4.0 * B * heads * (double)Tq * Tk * d,
                   2.0 * B * heads * d * (2.0 * Tq + 2.0 * Tk));
     }
-    c.err = launch_attention(q.p, k.p, v.p, out.p, B, Tq, Tk, heads, d, q.ld, k.ld, v.ld, out.ld, c.stream, causal);
+    c.err = launch_attention(q.p, k.p, v.p, out.p, B, Tq, Tk, heads, d, q.ld, k.ld, v.ld, out.ld, c.stream, causal, prescaled);
     prof_close(c.stream);
 }
 

@@ -7,6 +7,7 @@
 // up path (no torch.cat copies), fused qkv / GEGLU / residual / time-embedding epilogues, one
 // stacked GEMV for all 22 time_emb_proj layers, and a stack-discipline workspace arena.
 #include "model.h"
+#include <cmath>
 
 namespace sd {
 
@@ -162,6 +163,14 @@ int UNet::pack_xformer(const std::string& p, Xformer* x, int heads, int depth) {
         if ((rc = ws.pack_rows({q + ".attn1.to_q.weight", q + ".attn1.to_k.weight", q + ".attn1.to_v.weight"}, {}, &b.qkv))) return rc;
         if ((rc = ws.pack_conv(q + ".attn1.to_out.0", &b.out1))) return rc;
         if ((rc = ws.pack_conv(q + ".attn2.to_q", &b.q2, false))) return rc;
+        // fold softmax's log2(e)/sqrt(d) into both query projections (rows [0, C) of the fused q|k|v
+        // matrix and all of attn2.to_q; neither has a bias): the attention kernel then runs its
+        // `prescaled` path.  One extra fp16 rounding of weights that were fp16-rounded already.
+        {
+            const float qs = 1.4426950408889634f / sqrtf((float)(x->C / heads));
+            if ((rc = launch_scale_f16(b.qkv.w, (long)x->C * b.qkv.K, qs, 0))) return rc;
+            if ((rc = launch_scale_f16(b.q2.w, (long)x->C * b.q2.K, qs, 0))) return rc;
+        }
         // text K/V projections depend only on encoder_hidden_states: all of them are stacked into
         // one GEMM (kv_all) issued once per forward instead of one small launch per block
         b.kv_off = kv_total;
@@ -271,13 +280,13 @@ void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out
         View qkv(a.alloc_h(M * 3 * C), 3 * C, 3 * C);
         op_conv(c, b.qkv, n, N, H, W, qkv);
         View att(a.alloc_h(M * C), C, C);
-        op_attention(c, qkv.slice(0, C), qkv.slice(C, C), qkv.slice(2 * C, C), att, N, T, T, t.heads, d);
+        op_attention(c, qkv.slice(0, C), qkv.slice(C, C), qkv.slice(2 * C, C), att, N, T, T, t.heads, d, 0, 1);
         View t2(a.alloc_h(M * C), C, C);
         op_conv(c, b.out1, att, N, H, W, t2, 1, 0, nullptr, 0, &cur);
         op_layernorm(c, b.ln2, t2, n, M, 1e-5f);
         View q(a.alloc_h(M * C), C, C);
         op_conv(c, b.q2, n, N, H, W, q);
-        op_attention(c, q, text_kv.slice(b.kv_off, C), text_kv.slice(b.kv_off + C, C), att, N, T, L, t.heads, d);
+        op_attention(c, q, text_kv.slice(b.kv_off, C), text_kv.slice(b.kv_off + C, C), att, N, T, L, t.heads, d, 0, 1);
         View t3(a.alloc_h(M * C), C, C);
         op_conv(c, b.out2, att, N, H, W, t3, 1, 0, nullptr, 0, &t2);
         op_layernorm(c, b.ln3, t3, n, M, 1e-5f);

@@ -114,8 +114,8 @@ def test_causal_attention_op(engine_lib, B, T, heads, d):
     out = torch.empty_like(qd)
     P = lambda t: C.c_void_p(t.data_ptr())
     ld = heads * d
-    rc = engine_lib.sd_op_attention_causal(P(qd), P(kd), P(vd), P(out), B, T, T, heads, d, ld, ld, ld, ld,
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    rc = engine_lib.sd_op_attention_ex(P(qd), P(kd), P(vd), P(out), B, T, T, heads, d, ld, ld, ld, ld, 1, 0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, engine_lib.sd_last_error()
     torch.cuda.synchronize()
     assert rel_l2(out, ref) < 2e-3

@@ -198,3 +198,56 @@ def test_attention_online_softmax_rescale(engine_lib):
     torch.cuda.synchronize()
     assert rel_l2(out, ref) < 3e-3
     assert (out[0, 17].float().cpu() - ref[0, 17]).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("case", ATTN_CASES[:8] + [(1, 4096, 4096, 2, 40), (1, 300, 300, 2, 64)])
+@pytest.mark.parametrize("spike", [False, True])
+def test_attention_prescaled_queries(engine_lib, case, spike):
+    """The `prescaled` path the UNet uses: q arrives multiplied by log2(e)/sqrt(d) and the running
+    reference is subtracted through the MFMA accumulators.  Checked against SDPA of the SAME fp16
+    queries (un-scaled on the host in fp32), with and without a late score spike that forces the
+    reference to move, and with all-negative scores in the first tile (reference set downwards)."""
+    B, Tq, Tk, H, d = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    c = 1.4426950408889634 / d ** 0.5
+    qs = (torch.randn(B, Tq, H * d, generator=g) * c).half()          # what the scaled projection would emit
+    k = (torch.randn(B, Tk, H * d, generator=g) * (0.3 if spike else 1.0)).half()
+    v = torch.randn(B, Tk, H * d, generator=g).half()
+    if spike and Tk > 70:
+        k[:, Tk - 3] = (qs[:, min(17, Tq - 1)].float() / c * 2.0).half()   # big score in the last key tile
+        k[:, :64] -= 0                                                        # (first tile stays ordinary)
+    q_unscaled = qs.float() / c
+    ref = F.scaled_dot_product_attention(q_unscaled.view(B, Tq, H, d).transpose(1, 2),
+                                         k.float().view(B, Tk, H, d).transpose(1, 2),
+                                         v.float().view(B, Tk, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, Tq, H * d)
+    out = torch.empty(B, Tq, H * d, dtype=torch.float16, device="cuda")
+    qd, kd, vd = h(qs), h(k), h(v)
+    rc = engine_lib.sd_op_attention_ex(P(qd), P(kd), P(vd), P(out), B, Tq, Tk, H, d, H * d, H * d, H * d, H * d, 0, 1,
+                                       stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < 3e-3
+
+
+def test_attention_prescaled_very_negative_scores(engine_lib):
+    """All scores of a row far below zero (log2 domain): the first tile must pull the reference down,
+    otherwise every probability underflows and the row divides by zero."""
+    B, T, H, d = 1, 128, 1, 64
+    g = torch.Generator().manual_seed(11)
+    c = 1.4426950408889634 / d ** 0.5
+    base = torch.randn(1, 1, d, generator=g)
+    q = (base * 6.0).expand(B, T, d).clone()
+    k = (-base * 6.0 + 0.1 * torch.randn(B, T, d, generator=g))      # q.k ~ -36 * |base|^2 * ... : hugely negative
+    v = torch.randn(B, T, d, generator=g)
+    qs = (q * c).half()
+    ref = F.scaled_dot_product_attention((qs.float() / c).view(B, T, H, d).transpose(1, 2),
+                                         k.half().float().view(B, T, H, d).transpose(1, 2),
+                                         v.half().float().view(B, T, H, d).transpose(1, 2)).transpose(1, 2).reshape(B, T, d)
+    out = torch.empty(B, T, d, dtype=torch.float16, device="cuda")
+    qd, kd, vd = h(qs), h(k.half()), h(v.half())
+    rc = engine_lib.sd_op_attention_ex(P(qd), P(kd), P(vd), P(out), B, T, T, H, d, d, d, d, d, 0, 1, stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < 5e-3
