@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
             // s already holds (score - mrun) in log2 units.  The reference only has to keep exp2 inside
             // fp16: it moves (wave-uniformly) when some score exceeds it by 2^8, and on the first
             // tile, where it is set to the tile's own row maximum.
-            float mx[QT];
-            bool grow = kt0 == 0;
+            float mx[QT];                      // this lane's 16 keys only: enough to decide, wave-wide,
+            bool grow = kt0 == 0;              // whether anybody needs the reference moved
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 float m = -INFINITY;
@@ -243,14 +243,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                 for (int ksub = 0; ksub < NSUB; ++ksub)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) m = fmaxf(m, s[ksub][t][j]);
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
                 mx[t] = m;
                 grow |= m > kRescaleThreshold;
             }
             if (__any(grow)) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
+                    mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 16));     // the query's row maximum over the tile
+                    mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 32));
                     const float delta = kt0 == 0 ? mx[t] : fmaxf(mx[t], 0.f);
                     const float alpha = kt0 == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);   // o, l are 0 on tile 0
                     mrun[t] += delta;
