@@ -188,6 +188,12 @@ int sd_cfg_linear_step(const void* noise_pred_2b, void* latents, float* hist_f32
                        float guidance_scale, float c_x, float c_eps, float c_hist, float h_x, float h_eps,
                        void* stream);
 
+/* Inpainting with a 4-channel UNet, after every scheduler step (sd_unified_pipeline.py:492-506):
+ *   latents <- m latents + (1 - m) (a image_latents + b noise),  m = mask [B,1,H,W] f16 over channels;
+ * (a, b) = scheduler.add_noise coefficients at the NEXT timestep, or noise = NULL on the last step. */
+int sd_inpaint_blend(void* latents, const void* image_latents, const void* noise, const void* mask,
+                     float a, float b, int B, int C, int H, int W, void* stream);
+
 /* convert_pt_to_numpy (runpod-worker/handler_logic.py:21-29): decoded images [B,C,H,W] f16 in [-1,1] ->
  * [B,H,W,C] uint8, with the reference's fp16 roundings and truncating cast (bit-exact with running
  * the reference's op sequence on the same fp16 tensor).  C <= 4. */

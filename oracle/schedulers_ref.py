@@ -144,6 +144,12 @@ class EulerRef:
         s = self.sigmas[self.i]
         return x / np.sqrt(s * s + 1.0)
 
+    def add_noise(self, x0, noise, t):
+        """diffusers EulerDiscreteScheduler.add_noise: sigma-space, x0 + sigma(t) * noise, sigma looked up
+        at the schedule position of `t` (index_for_timestep: first match)."""
+        idx = int(np.nonzero(np.isclose(self.timesteps, float(t)))[0][0])
+        return x0 + self.sigmas[idx] * noise
+
     def step(self, eps, t, x):
         s = self.sigmas[self.i]
         x0 = x - s * eps

@@ -108,6 +108,7 @@ SIGNATURES = {
     "sd_op_attention_ex": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sd_cfg_duplicate": (_I, [_P, _P, _I64, _I, _F, _P]),
     "sd_cfg_ddim_step": (_I, [_P, _P, _I64, _F, _F, _F, _P]),
+    "sd_inpaint_blend": (_I, [_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P]),
     "sd_images_to_uint8": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sd_cfg_linear_step": (_I, [_P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _P]),
     "sd_igemm_force": (_I, [_I, _I]),

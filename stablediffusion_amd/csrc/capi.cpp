@@ -201,6 +201,16 @@ int sd_images_to_uint8(const void* images_nchw_f16, void* out_nhwc_u8, int B, in
     return launch_image_to_uint8(static_cast<const half_t*>(images_nchw_f16), static_cast<unsigned char*>(out_nhwc_u8), B, C,
                                  (long)H * W, static_cast<hipStream_t>(stream));
 }
+int sd_inpaint_blend(void* latents, const void* image_latents, const void* noise, const void* mask, float a, float b,
+                     int B, int C, int H, int W, void* stream) {
+    if (!latents || !image_latents || !mask || B < 0 || C < 1 || H < 1 || W < 1) {
+        set_error("sd_inpaint_blend: bad arguments");
+        return SD_ERR_INVALID;
+    }
+    return launch_inpaint_blend(static_cast<half_t*>(latents), static_cast<const half_t*>(image_latents),
+                                static_cast<const half_t*>(noise), static_cast<const half_t*>(mask), a, b, B, C,
+                                (long)H * W, static_cast<hipStream_t>(stream));
+}
 int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float guidance_scale, float c_x,
                      float c_eps, void* stream) {
     if (!noise_pred_2b || !latents) { set_error("null argument"); return SD_ERR_INVALID; }

@@ -92,6 +92,8 @@ int launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half
 // out[b, :] = x[b * T + idx[b], :] as f16 (out16) and / or f32 (out32); idx clamped to [0, T)
 int launch_gather_rows(const half_t* x, long ldx, const int* idx, half_t* out16, float* out32, int B, int T, int H,
                        hipStream_t s);
+int launch_inpaint_blend(half_t* lat, const half_t* img, const half_t* noise, const half_t* mask, float a, float b, int B,
+                         int C, long HW, hipStream_t s);
 int launch_scale_f16(half_t* x, long n, float scale, hipStream_t s);     // x *= scale (fp32 multiply, one rounding)
 int launch_image_to_uint8(const half_t* img, unsigned char* out, int B, int C, long HW, hipStream_t s);
 int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, float g, float cx, float ce, float ch,

@@ -272,6 +272,21 @@ __global__ void gather_rows_kernel(const half_t* __restrict__ x, long ldx, const
     if (out32) out32[i] = (float)v;
 }
 
+// Inpainting with a 4-channel UNet (sd_unified_pipeline.py:492-506): outside the mask the latents are
+// reset to the (re-noised) original image latents after every step.
+//   x <- m x + (1 - m) (a img + b noise),  m = mask[b, 0, h, w] broadcast over channels
+__global__ void inpaint_blend_kernel(half_t* __restrict__ lat, const half_t* __restrict__ img,
+                                     const half_t* __restrict__ noise, const half_t* __restrict__ mask, float a,
+                                     float b, int C, long HW, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long bc = i / HW, px = i - bc * HW;
+    const float m = (float)mask[(bc / C) * HW + px];
+    float keep = a * (float)img[i];
+    if (noise) keep += b * (float)noise[i];
+    lat[i] = (half_t)(m * (float)lat[i] + (1.f - m) * keep);
+}
+
 __global__ void scale_f16_kernel(half_t* __restrict__ x, long n, float scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = (half_t)((float)x[i] * scale);
@@ -368,6 +383,14 @@ int launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half
 int launch_gather_rows(const half_t* x, long ldx, const int* idx, half_t* out16, float* out32, int B, int T, int H,
                        hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, grid1d((long)B * H), dim3(256), 0, s, x, ldx, idx, out16, out32, B, T, H);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_inpaint_blend(half_t* lat, const half_t* img, const half_t* noise, const half_t* mask, float a, float b, int B,
+                         int C, long HW, hipStream_t s) {
+    const long n = (long)B * C * HW;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(inpaint_blend_kernel, grid1d(n), dim3(256), 0, s, lat, img, noise, mask, a, b, C, HW, n);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

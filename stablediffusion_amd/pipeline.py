@@ -269,13 +269,22 @@ class StableDiffusionUnifiedPipeline:
         # the UNet forward of every step.  One copy of the schedule to the host before the loop
         # removes those 50 bubbles; the values are the same.
         timesteps_host = [float(v) for v in timesteps.tolist()]
-        fused_step = self._fused_step_available(model, latents)
+        fused_step = self._fused_step_available(model, latents, num_channels_unet)
         fused_hist = None
+        blend = None
+        if fused_step and self.is_inpaint:       # 4-channel inpainting: device-side blend after every step
+            f16 = lambda x: x.to(device=latents.device, dtype=torch.float16).contiguous()
+            m1 = mask.chunk(2)[0] if self.do_classifier_free_guidance else mask
+            blend = (f16(image_latents), f16(noise), f16(m1.expand(latents.shape[0], 1, *latents.shape[2:])))
         for i, t in enumerate(timesteps_host):
             if fused_step:
                 latents, fused_hist = self._fused_cfg_iteration(model, latents, fused_hist, t, prompt_embeds,
                                                                 cross_attention_kwargs, added_cond_kwargs,
                                                                 guidance_scale)
+                if blend is not None:
+                    last = i == len(timesteps_host) - 1
+                    a, b = (1.0, 0.0) if last else model.scheduler.add_noise_coefficients(timesteps_host[i + 1])
+                    self._device_inpaint_blend(model, latents, blend, a, b, with_noise=not last)
                 continue
             latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
             latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
@@ -316,14 +325,26 @@ class StableDiffusionUnifiedPipeline:
         return images
 
     # ------------------------------------------------------------------------------------------
-    def _fused_step_available(self, model, latents) -> bool:
+    def _device_inpaint_blend(self, model, latents, blend, a, b, with_noise):
+        import ctypes as C
+        lib = model.base._lib
+        img, noise, m = blend
+        B, Cc, H, W = latents.shape
+        rc = lib.sd_inpaint_blend(C.c_void_p(latents.data_ptr()), C.c_void_p(img.data_ptr()),
+                                  C.c_void_p(noise.data_ptr()) if with_noise else None, C.c_void_p(m.data_ptr()),
+                                  float(a), float(b), B, Cc, H, W, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc:
+            raise RuntimeError(lib.sd_last_error().decode())
+
+    def _fused_step_available(self, model, latents, num_channels_unet=4) -> bool:
         """CFG combine + scheduler update as ONE device kernel each side of the UNet:
         the scheduler still computes its coefficients on the host (`fused_plan`: DDIM, Euler, DPM++ 2M are
         all affine in x, eps and the previous x0 prediction), the engine applies them
-        (`sd_cfg_duplicate`, `sd_cfg_linear_step`).  Only for the plain txt2img / img2img loop with CFG on
-        the HIP engine; everything else takes the generic path."""
-        return (self.do_classifier_free_guidance and not self.is_inpaint
-                and hasattr(model.scheduler, "fused_plan")
+        (`sd_cfg_duplicate`, `sd_cfg_linear_step`), and for inpainting with a 4-channel UNet the mask blend
+        of `:492-506` follows as a third kernel (`sd_inpaint_blend`).  Only with CFG on the HIP engine;
+        9-channel inpainting UNets and non-CFG calls take the generic path."""
+        return (self.do_classifier_free_guidance and (not self.is_inpaint or num_channels_unet == 4)
+                and hasattr(model.scheduler, "fused_plan") and hasattr(model.scheduler, "add_noise_coefficients")
                 and hasattr(model.base, "_lib") and latents.is_cuda and latents.dtype == torch.float16)
 
     def _fused_cfg_iteration(self, model, latents, hist, t, prompt_embeds, cross_attention_kwargs, added_cond_kwargs,

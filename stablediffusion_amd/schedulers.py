@@ -60,6 +60,11 @@ class _Base:
     def scale_model_input(self, sample, timestep=None):
         return sample
 
+    def add_noise_coefficients(self, timestep):
+        """(a, b) of add_noise(x0, noise, t) = a x0 + b noise for one timestep (host floats)."""
+        t = int(timestep)
+        return float(self.ac[t] ** 0.5), float((1 - self.ac[t]) ** 0.5)
+
     def add_noise(self, original, noise, timesteps):
         t = torch.as_tensor(timesteps).reshape(-1).long().cpu().numpy()
         a = torch.tensor(self.ac[t] ** 0.5, dtype=torch.float32, device=original.device)
@@ -202,6 +207,21 @@ class EulerDiscreteScheduler(_Base):
     def scale_model_input(self, sample, timestep=None):
         s = self.sigmas[self._i]
         return (sample.float() / float((s * s + 1) ** 0.5)).to(sample.dtype)
+
+    def add_noise_coefficients(self, timestep):
+        ts = self.timesteps.double().cpu().numpy()
+        return 1.0, float(self.sigmas[int(np.abs(ts - float(timestep)).argmin())])
+
+    def add_noise(self, original, noise, timesteps):
+        """sigma-space noising (diffusers EulerDiscreteScheduler.add_noise): x0 + sigma(t) * noise with
+        sigma taken at the schedule position of each timestep (first match, else the nearest)."""
+        ts = self.timesteps.double().cpu().numpy()
+        want = torch.as_tensor(timesteps).reshape(-1).double().cpu().numpy()
+        idx = [int(np.abs(ts - w).argmin()) for w in want]
+        s = torch.tensor(self.sigmas[idx], dtype=torch.float32, device=original.device)
+        while s.ndim < original.ndim:
+            s = s.unsqueeze(-1)
+        return (original.float() + s * noise.float()).to(original.dtype)
 
     def fused_plan(self, timestep=None):
         s, s_next = self.sigmas[self._i], self.sigmas[self._i + 1]

@@ -277,6 +277,39 @@ def test_fused_device_step_equals_host_scheduler_loop(engine_lib, sched):
     assert rel_l2(fused, host) < 3e-3
 
 
+@pytest.mark.parametrize("sched", ["DDIM", "euler"])
+def test_inpaint_device_blend_equals_host_loop(engine_lib, sched):
+    """4-channel inpainting (sd_unified_pipeline.py:268-380, :492-506) with the per-step mask blend on the
+    device (sd_inpaint_blend) against the same engine driven through the host torch blend; outside the
+    mask the result is the encoded original."""
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = config.tiny_unet(), config.tiny_vae()
+    usd = _f16_round(weights.synth_state_dict(weights.unet_manifest(ucfg), 11))
+    vsd = _f16_round(weights.synth_state_dict(weights.vae_manifest(vcfg), 12))
+    model = SDModelWrapper(base=HipUNet2DConditionModel(ucfg).load_state_dict(usd),
+                           vae=HipAutoencoderKL(vcfg).load_state_dict(vsd), scheduler=DDIMScheduler(), device="cuda")
+    model.set_scheduler(sched)
+    g = torch.Generator().manual_seed(4)
+    pos = torch.randn(1, 7, ucfg.cross_attention_dim, generator=g).half().cuda()
+    neg = torch.randn(1, 7, ucfg.cross_attention_dim, generator=g).half().cuda()
+    image = torch.randn(1, 3, 128, 128, generator=g).clamp(-1, 1).half().cuda()
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, :, 64:] = 1.0
+    kw = dict(prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask.cuda(), num_inference_steps=4,
+              seed=2, guidance_scale=5.0)
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda", output_type="latents")
+    fused = pipe(model, **kw)
+    assert pipe._fused_step_available(model, fused, 4)
+    host_pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda", output_type="latents")
+    host_pipe._fused_step_available = lambda *a: False
+    host = host_pipe(model, **kw)
+    assert torch.isfinite(fused.float()).all() and rel_l2(fused, host) < 3e-3
+    w = fused.shape[-1]
+    assert torch.allclose(fused[..., : w // 2].float(), host[..., : w // 2].float(), atol=2e-3)   # kept region
+    assert not torch.allclose(fused[..., w // 2:].float(), fused[..., : w // 2].float().flip(-1), atol=1e-2)
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size SD1.5 (BASELINE.json config C1: 256x256, 10-step DDIM, batch 1, CFG on)
 # ---------------------------------------------------------------------------------------------

@@ -82,6 +82,25 @@ def test_product_schedulers_match_oracle(name, ref_cls, n):
         assert np.allclose(x.numpy(), xr, atol=1e-5), (name, float(t))
 
 
+@pytest.mark.parametrize("name,ref_cls", [("DDIM", schedulers_ref.DDIMRef), ("euler", schedulers_ref.EulerRef)])
+def test_add_noise_matches_oracle(name, ref_cls):
+    """img2img / inpaint noising (`sd_unified_pipeline.py:502, :841`): alpha-space for DDIM, sigma-space
+    for Euler (x0 + sigma(t) noise) -- and the two really differ."""
+    prod = schedulers.REGISTRY[name](schedulers.DDIMScheduler().config)
+    ref = ref_cls()
+    prod.set_timesteps(10)
+    ref.set_timesteps(10)
+    g = torch.Generator().manual_seed(4)
+    x0, noise = torch.randn(2, 4, 8, 8, generator=g).double(), torch.randn(2, 4, 8, 8, generator=g).double()
+    for t in prod.timesteps[[0, 3, 9]]:
+        got = prod.add_noise(x0, noise, torch.as_tensor([float(t)]))
+        assert np.allclose(got.numpy(), ref.add_noise(x0.numpy(), noise.numpy(), float(t)), atol=1e-6)
+    if name == "euler":
+        t = prod.timesteps[3]
+        base = schedulers.DDIMScheduler.add_noise(prod, x0, noise, torch.as_tensor([int(t)]))
+        assert not np.allclose(base.numpy(), prod.add_noise(x0, noise, torch.as_tensor([float(t)])).numpy(), atol=1e-2)
+
+
 def test_ddim_affine_coefficients():
     s = schedulers.DDIMScheduler()
     s.set_timesteps(50)
