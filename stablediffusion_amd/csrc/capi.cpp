@@ -300,6 +300,12 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
         // SD_BENCH_COLD_MB=<n> (tuner): rotate through copies of the packed weights totalling n MB, so
         // every timed launch streams its weights from HBM as it does inside a UNet forward (1.7 GB of
         // weights per forward never stay in the 256 MB Infinity Cache); unset = same buffer every launch.
+        half_t* res_bench = nullptr;   // SD_BENCH_RES=1 (tuner): time the launch with the fused residual add
+        if (ms_out && !res && getenv("SD_BENCH_RES")) {
+            SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&res_bench), (size_t)p.M * ocols * sizeof(half_t)));
+            SD_HIP_CHECK(hipMemsetAsync(res_bench, 0, (size_t)p.M * ocols * sizeof(half_t), s));
+            p.res = res_bench;
+        }
         half_t* wring = nullptr;
         long nrot = 1;
         const size_t wbytes = (size_t)rows * K * sizeof(half_t);
@@ -331,6 +337,7 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
         }
         if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
         if (wring) { (void)hipStreamSynchronize(s); (void)hipFree(wring); }
+        if (res_bench) { (void)hipStreamSynchronize(s); (void)hipFree(res_bench); }
     }
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(wp); (void)hipFree(bp);
