@@ -20,6 +20,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -91,6 +92,27 @@ def pmc_traffic_for(kernel_label: str):
             "source": "profiles/r01_pmc_hbm_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                       "separate passes, FETCH_SIZE doubled for gfx950; average over all launches of the kernel "
                       "in that run)"}
+
+
+def rocprof_avg_us_for(kernel_label: str):
+    """Average duration of the roofline kernel in the committed rocprofv3 --kernel-trace --stats summary of
+    this same command (profiles/r01_bench_kernel_stats.csv).  The live HIP-event bracket reads ~10 % longer
+    than the trace: an event between two launches keeps the next kernel's ramp from overlapping the
+    previous kernel's tail, which is how the kernels run in the timed loop."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    want = kernel_label.replace(" ", "")
+    m = re.match(r"(\w+)<(\d+)>$", want)          # e.g. attn_kernel<40> -> mangled attn_kernelILi40E...
+    mangled = f"{m.group(1)}ILi{m.group(2)}E" if m else None
+    tot = n = 0.0
+    for row in csv.DictReader(open(path)):
+        name = row["Name"].replace(" ", "")
+        if want in name or (mangled and mangled in name):
+            tot += float(row["TotalDurationNs"])
+            n += float(row["Calls"])
+    return round(tot / n / 1e3, 2) if n else None
 
 
 def usable_cores() -> int:
@@ -297,6 +319,7 @@ def main():
                                       "launches_per_unet_forward": launches,
                                       "algorithmic_MB_per_launch": round(nbytes / launches / 1e6, 2),
                                       "avg_launch_us": round(ms / launches * 1e3, 2),
+                                      "rocprofv3_avg_launch_us": rocprof_avg_us_for(name),
                                       "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3)}
             else:
                 ach = nbytes / (ms / 1e3) / 1e9
