@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     constexpr int NKK = KT / 32;                         // 32-key k-steps of the PV product
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int KS = DK / 32;
-    constexpr int DT = (D + 15) / 16;
+    // PV row tiles; head dims that fill their last tile (32, 64) get one more, so that the ones column
+    // can ride there: 4 extra MFMAs per key tile buy back 32 v_add_f32 per lane (VALU issue is the limit)
+    constexpr int DT = (D + 15) / 16 + ((D % 16 == 0 && D <= 64) ? 1 : 0);
     constexpr int KSTR = odd32_bytes(DK * 2) / 2;        // halves
     constexpr int VSTR = odd32_bytes(DT * 16 * 2) / 2;   // halves
     constexpr int CH = D / 8;                            // real 16-byte chunks per row
@@ -382,7 +384,7 @@ template <int D, int QT, int KT, bool PRESC>
 int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq, int Tk,
                 int heads, long ldq, long ldk, long ldv, long ldo, int causal, bool q_has_scale, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32;
-    constexpr int DT = (D + 15) / 16;
+    constexpr int DT = (D + 15) / 16 + ((D % 16 == 0 && D <= 64) ? 1 : 0);
     constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
     static bool attr_set = false;
     if (!attr_set) {
