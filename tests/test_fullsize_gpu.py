@@ -1,0 +1,149 @@
+"""Parity at BASELINE.json's FULL sizes (C2: CFG batch 8 at 64x64 latents + the 512 px decode; C5: 96x96;
+C4: SDXL at 128x128), where the tile variants, split-K choices and norm kernels are the ones the benchmark
+runs -- the CPU oracle only finishes in seconds at C1 size.  The checker here is the same oracle code
+(`oracle/unet_ref.py`, `oracle/vae_ref.py`) evaluated in fp32 ON THE GPU through PyTorch-ROCm (MIOpen /
+rocBLAS fp32, TF32-style shortcuts disabled): an implementation independent of the engine's kernels,
+itself first pinned to its own CPU evaluation at small size (`test_gpu_evaluation_of_the_oracle_...`).
+Tolerance: relative L2 <= 1e-2 (BASELINE.json), measured values are ~2e-3."""
+import os
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # the checker's fp32 convs: skip MIOpen's exhaustive kernel search
+
+import pytest  # noqa: E402
+import torch  # noqa: E402
+
+from conftest import rel_l2  # noqa: E402
+from oracle import unet_ref, vae_ref  # noqa: E402
+from stablediffusion_amd import config, weights  # noqa: E402
+from stablediffusion_amd.models import HipAutoencoderKL, HipUNet2DConditionModel  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2
+
+
+@pytest.fixture(autouse=True)
+def _true_fp32():
+    old = (torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32)
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+    torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = old
+
+
+def oracle_unet_on_gpu(cfg, sd16, x, t, ehs, added=None):
+    """unet_ref.unet_forward with every tensor on cuda in fp32 (the sinusoid table is built on the host)."""
+    w = {k: v.float().cuda() for k, v in sd16.items()}
+    orig = unet_ref.timestep_sinusoid
+    unet_ref.timestep_sinusoid = lambda tt, *a, **k: orig(tt.cpu(), *a, **k).cuda()
+    try:
+        with torch.no_grad():
+            add = {k: v.float().cuda() for k, v in added.items()} if added else None
+            kw = {"added_cond_kwargs": add} if add else {}
+            return unet_ref.unet_forward(cfg, w, x.float().cuda(), t, ehs.float().cuda(), **kw)
+    finally:
+        unet_ref.timestep_sinusoid = orig
+
+
+def test_gpu_evaluation_of_the_oracle_equals_its_cpu_evaluation(engine_lib):
+    ucfg, vcfg = config.tiny_unet(), config.tiny_vae()
+    usd = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=3, dtype=torch.float16, perturb=0.1)
+    vsd = weights.synth_state_dict(weights.vae_manifest(vcfg), seed=4, dtype=torch.float16, perturb=0.1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 16, 16, generator=g).half()
+    ehs = torch.randn(2, 9, ucfg.cross_attention_dim, generator=g).half()
+    with torch.no_grad():
+        cpu = unet_ref.unet_forward(ucfg, {k: v.float() for k, v in usd.items()}, x.float(), torch.tensor(333.0), ehs.float())
+        cpu_img = vae_ref.vae_decode(vcfg, {k: v.float() for k, v in vsd.items()}, x[:1].float())
+        gpu_img = vae_ref.vae_decode(vcfg, {k: v.float().cuda() for k, v in vsd.items()}, x[:1].float().cuda())
+    gpu = oracle_unet_on_gpu(ucfg, usd, x, torch.tensor(333.0), ehs)
+    assert rel_l2(gpu, cpu) < 1e-4 and rel_l2(gpu_img, cpu_img) < 1e-4
+
+
+@pytest.mark.parametrize("name,B,hw", [("C2 (512 px, CFG batch 8)", 8, 64), ("C5 (768 px img2img, CFG batch 8)", 8, 96)])
+def test_sd15_unet_at_benchmark_size(engine_lib, name, B, hw):
+    cfg = config.sd15_unet()
+    sd = weights.synth_state_dict(weights.unet_manifest(cfg), seed=41, dtype=torch.float16, perturb=0.1)
+    net = HipUNet2DConditionModel(cfg).load_state_dict(sd)
+    g = torch.Generator().manual_seed(hw)
+    x = torch.randn(B, 4, hw, hw, generator=g).half()
+    ehs = torch.randn(B, 77, 768, generator=g).half()
+    got = net(x.cuda(), torch.tensor(501.0), ehs.cuda())[0]
+    ref = oracle_unet_on_gpu(cfg, sd, x, torch.tensor(501.0), ehs)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < TOL, name
+
+
+def test_sd15_vae_decode_at_benchmark_size(engine_lib):
+    cfg = config.sd15_vae()
+    sd = weights.synth_state_dict(weights.vae_manifest(cfg), seed=42, dtype=torch.float16, perturb=0.1)
+    vae = HipAutoencoderKL(cfg).load_state_dict(sd)
+    z = (torch.randn(4, 4, 64, 64, generator=torch.Generator().manual_seed(6)) * 1.5).half()
+    got = vae.decode(z.cuda())[0]
+    with torch.no_grad():
+        ref = vae_ref.vae_decode(cfg, {k: v.float().cuda() for k, v in sd.items()}, z.float().cuda())
+    assert got.shape == (4, 3, 512, 512) and rel_l2(got, ref) < TOL
+    # and the encoder on the 512 px images (img2img / inpaint prep, C5's first step)
+    img = got.clamp(-1, 1)
+    enc = vae.encode_moments(img)
+    with torch.no_grad():
+        ref_m = vae_ref.vae_encode_moments(cfg, {k: v.float().cuda() for k, v in sd.items()}, img.float())
+    assert rel_l2(enc[:, :4], ref_m[:, :4]) < TOL              # the means (log-variances are clamped to [-30, 20])
+
+
+def test_sdxl_unet_at_benchmark_size(engine_lib):
+    """C4: SDXL-base UNet, CFG batch 4 at 128x128 latents (1024 px), text_time conditioning."""
+    cfg = config.sdxl_unet()
+    sd = weights.synth_state_dict(weights.unet_manifest(cfg), seed=43, dtype=torch.float16, perturb=0.1)
+    net = HipUNet2DConditionModel(cfg).load_state_dict(sd)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 4, 128, 128, generator=g).half()
+    ehs = torch.randn(4, 77, 2048, generator=g).half()
+    added = {"text_embeds": torch.randn(4, 1280, generator=g).half(),
+             "time_ids": torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * 4)}
+    got = net(x.cuda(), torch.tensor(741.0), ehs.cuda(),
+              added_cond_kwargs={k: v.cuda() for k, v in added.items()})[0]
+    ref = oracle_unet_on_gpu(cfg, sd, x, torch.tensor(741.0), ehs, added)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < TOL
+
+
+@pytest.mark.parametrize("steps", [10, 50])
+def test_c2_loop_and_decode_at_benchmark_size(engine_lib, steps):
+    """BASELINE.json C2 through the whole path: 4 latents at 64x64, CFG on, DDIM with 10 steps and with the
+    benchmark's own 50, VAE decode to 512 px -- engine pipeline against the oracle loop (numpy float64
+    scheduler, fp32 UNet / VAE evaluated on the GPU).  Also states the result in the uint8 pixel domain of
+    `handler_logic.py:21-29`."""
+    from oracle import pipeline_ref
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = config.sd15_unet(), config.sd15_vae()
+    usd = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=51, dtype=torch.float16)
+    vsd = weights.synth_state_dict(weights.vae_manifest(vcfg), seed=52, dtype=torch.float16)
+    model = SDModelWrapper(base=HipUNet2DConditionModel(ucfg).load_state_dict(usd),
+                           vae=HipAutoencoderKL(vcfg).load_state_dict(vsd), scheduler=DDIMScheduler(), device="cuda")
+    g = torch.Generator().manual_seed(12)
+    lat0 = torch.randn(4, 4, 64, 64, generator=g).half()
+    neg, pos = torch.randn(4, 77, 768, generator=g).half(), torch.randn(4, 77, 768, generator=g).half()
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda")
+    images = pipe(model, prompt_embeds=pos.cuda(), negative_prompt_embeds=neg.cuda(), latents=lat0.cuda(),
+                  num_inference_steps=steps, guidance_scale=5.0, height=512, width=512)
+    # the oracle loop with its UNet / VAE calls routed to the GPU evaluation
+    uw = {k: v.float().cuda() for k, v in usd.items()}
+    vw = {k: v.float().cuda() for k, v in vsd.items()}
+    emb2 = torch.cat([neg, pos]).float()
+    orig_u, orig_v, orig_s = pipeline_ref.unet_forward, pipeline_ref.vae_decode, unet_ref.timestep_sinusoid
+    pipeline_ref.unet_forward = lambda c, w, x, t, e, a=None: orig_u(c, w, x.cuda(), t, e.cuda(), a).cpu()
+    pipeline_ref.vae_decode = lambda c, w, z: orig_v(c, w, z.cuda()).cpu()
+    unet_ref.timestep_sinusoid = lambda tt, *a, **k: orig_s(tt.cpu(), *a, **k).cuda()
+    try:
+        ref_img, ref_lat = pipeline_ref.txt2img_ref(ucfg, uw, vcfg, vw, lat0.float(), emb2, steps=steps, guidance_scale=5.0)
+    finally:
+        pipeline_ref.unet_forward, pipeline_ref.vae_decode, unet_ref.timestep_sinusoid = orig_u, orig_v, orig_s
+    assert images.shape == (4, 3, 512, 512) and torch.isfinite(images.float()).all()
+    print(f"c2 loop, {steps} steps: image rel-L2", rel_l2(images, ref_img))
+    assert rel_l2(images, ref_img) < TOL
+    u8 = pipeline_ref.to_uint8_hwc(images.float().cpu()).astype(int)
+    u8_ref = pipeline_ref.to_uint8_hwc(ref_img).astype(int)
+    diff = abs(u8 - u8_ref)
+    print(f"c2 loop, {steps} steps: uint8 mean |d|", diff.mean(), "within 4 levels", (diff <= 4).mean())
+    assert diff.mean() <= 1.0 and (diff <= 4).mean() >= 0.995
