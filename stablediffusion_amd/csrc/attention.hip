@@ -19,8 +19,12 @@
 //     grows by less than 2^8 -- probabilities stay below 256, well inside fp16.
 //   * K / V tiles of 64 keys in LDS with row strides that are odd multiples of 32 bytes:
 //     conflict-free for both ds_read_b128 fragment reads and the transposed reads.  Tiles are
-//     double-buffered in LDS and prefetched two tiles ahead through registers, so there is ONE
-//     barrier per tile (PMC showed waves 40 % of their time in s_waitcnt/barrier with two).
+//     double-buffered in LDS and filled by LDS-DMA (buffer_load ... lds, 16 B per lane) one tile
+//     ahead: no staging registers, no VALU address work in the loop, ONE barrier per tile (PMC
+//     showed waves 40 % of their time in s_waitcnt/barrier with two).  The padded LDS rows map to
+//     DMA slots; pad chunks are masked off so the zero / ones padding written once survives, rows
+//     past the last key read out of range and land as zeros.  Against staging through registers:
+//     -8 % at d = 64, -11 % at d = 80, -18 % at d = 160 (d = 40 is bound by exp / cvt / max issue).
 //     Measured and rejected: 128-key tiles (fewer barriers, more registers: 10-30 % slower) and
 //     64 queries per wave for d = 64 / 80 (slower); d = 40 runs 64 queries per wave (QT = 4).
 //   * head dims 40 / 80 / 160 (SD1.5), 64 (SDXL), 512 (VAE), 32 / 128 (test configs); the QK^T
@@ -30,7 +34,7 @@
 namespace sd {
 namespace {
 
-constexpr float kRescaleThreshold = 8.0f;   // log2 units
+[[maybe_unused]] constexpr float kRescaleThreshold = 8.0f;   // log2 units
 
 constexpr int odd32_bytes(int bytes) { return ((((bytes + 31) / 32) | 1)) * 32; }
 
@@ -48,6 +52,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
                                                    int heads, long ldq, long ldk, long ldv,
                                                    long ldo, float scale_log2e, int causal) {
     static_assert(KT == 64 || KT == 128, "keys per tile");
+    // The body is device-only: clang's host pass cannot type-check the gfx950 16-byte LDS-DMA builtin
+    // inside a template and would silently drop the kernel's host stub (same as igemm2.hip).
+#if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NSUB = KT / 16;                        // 16-key subtiles per tile
     constexpr int NKK = KT / 32;                         // 32-key k-steps of the PV product
     constexpr int DK = (D + 31) / 32 * 32;
@@ -59,7 +66,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     constexpr int VSTR = odd32_bytes(DT * 16 * 2) / 2;   // halves
     constexpr int CH = D / 8;                            // real 16-byte chunks per row
     constexpr int NCH = KT * CH;                         // chunk slots per tile (K and V alike)
-    constexpr int LIT = (NCH + 255) / 256;               // staging iterations per thread
     constexpr bool ONES = DT * 16 > D;                   // spare PV rows -> denominator via MFMA
     constexpr bool PREFETCH = D <= 160;                  // register-staged prefetch of the next tile
     constexpr int QB = 64 * QT;                          // queries per block
@@ -134,46 +140,67 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 #pragma unroll
     for (int t = 0; t < QT; ++t) negm[t] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // staging registers (next tile)
-    h8 kreg[PREFETCH ? LIT : 1], vreg[PREFETCH ? LIT : 1];
-    auto load_tile = [&](int kt0) {
+    // ---- K / V tiles go global -> LDS by DMA (buffer_load ... lds, 16 B per lane, 1 KiB per wave
+    //      instruction), no register staging: slot p = 64 * instr + lane of a tile is (row p / SPR, chunk
+    //      p % SPR) of the padded LDS row, so a lane's source is fixed up to the tile's row offset.
+    //      Pad chunks are left alone (zeros / the ones column written once above); rows past Tk read
+    //      out of range and land as zeros. ----
+    constexpr unsigned kOOB = 0x80000000u;
+    constexpr int SPRK = KSTR / 8, SPRV = VSTR / 8;           // 16-byte slots per padded row = DMA instrs per tile
+    constexpr int NKW = (SPRK + 3) / 4, NVW = (SPRV + 3) / 4; // per wave
+    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kb), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vb), 0, 0x7fffffff, 0x00020000);
+    int k_row[NKW], k_off[NKW], v_row[NVW], v_off[NVW];       // off < 0: pad chunk, lane sits out
 #pragma unroll
-        for (int i = 0; i < LIT; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx / CH, c = (idx - r * CH) * 8;
-            h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < NCH && kt0 + r < Tk) {
-                kv = *reinterpret_cast<const h8*>(kb + (long)(kt0 + r) * ldk + c);
-                vv = *reinterpret_cast<const h8*>(vb + (long)(kt0 + r) * ldv + c);
+    for (int j = 0; j < NKW; ++j) {
+        const int p = (wave + 4 * j) * 64 + lane;
+        const int r = p / SPRK, c = p - r * SPRK;
+        k_row[j] = r;
+        k_off[j] = c < CH ? (int)((r * ldk + c * 8) * 2) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < NVW; ++j) {
+        const int p = (wave + 4 * j) * 64 + lane;
+        const int r = p / SPRV, c = p - r * SPRV;
+        v_row[j] = r;
+        v_off[j] = c < CH ? (int)((r * ldv + c * 8) * 2) : -1;
+    }
+    auto issue_tile = [&](int bufi, int kt0) {
+        half_t* dK = sK + bufi * TILE_HALVES;
+        half_t* dV = sV + bufi * TILE_HALVES;
+        const unsigned kbase = (unsigned)((long)kt0 * ldk * 2), vbase = (unsigned)((long)kt0 * ldv * 2);
+#pragma unroll
+        for (int j = 0; j < NKW; ++j) {
+            const int i = wave + 4 * j;
+            if (i < SPRK && k_off[j] >= 0) {
+                const unsigned voff = kt0 + k_row[j] < Tk ? kbase + (unsigned)k_off[j] : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(dK + i * 512), 16,
+                                                         voff, 0, 0, 0);
             }
-            kreg[i] = kv; vreg[i] = vv;
         }
-    };
-    auto store_tile = [&](int bufi) {
 #pragma unroll
-        for (int i = 0; i < LIT; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx / CH, c = (idx - r * CH) * 8;
-            if (idx < NCH) {
-                *reinterpret_cast<h8*>(sK + bufi * TILE_HALVES + r * KSTR + c) = kreg[i];
-                *reinterpret_cast<h8*>(sV + bufi * TILE_HALVES + r * VSTR + c) = vreg[i];
+        for (int j = 0; j < NVW; ++j) {
+            const int i = wave + 4 * j;
+            if (i < SPRV && v_off[j] >= 0) {
+                const unsigned voff = kt0 + v_row[j] < Tk ? vbase + (unsigned)v_off[j] : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dV + i * 512), 16,
+                                                         voff, 0, 0, 0);
             }
         }
     };
     if (PREFETCH) {
-        load_tile(0);
-        store_tile(0);
-        if (KT < Tk) load_tile(KT);
-        __syncthreads();                       // tile 0 and the padding of both buffers are in place
+        __syncthreads();                       // the padding of both buffers is in place before any tile lands
+        issue_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
     int cur = 0;
     for (int kt0 = 0; kt0 < Tk; kt0 += KT) {
         if (PREFETCH) {
-            // registers hold tile t+1: park it in the other buffer (last read one iteration ago,
-            // fenced by the barrier that closed that iteration), then fetch tile t+2
-            if (kt0 + KT < Tk) store_tile(cur ^ 1);
-            if (kt0 + 2 * KT < Tk) load_tile(kt0 + 2 * KT);
+            // tile t+1 streams into the other buffer (last read one iteration ago, fenced by the barrier
+            // that closed that iteration) while this one is consumed
+            if (kt0 + KT < Tk) issue_tile(cur ^ 1, kt0 + KT);
         } else {
             __syncthreads();                   // previous tile fully consumed (and padding written)
             for (int idx = tid; idx < NCH; idx += 256) {
@@ -347,6 +374,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
             }
         }
         if (PREFETCH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t+1 has landed
             __syncthreads();     // the one barrier per tile: publishes tile t+1, retires buffer `cur`
             cur ^= 1;
         }
@@ -378,6 +406,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
             }
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 template <int D, int QT, int KT, bool PRESC>
@@ -411,9 +440,9 @@ int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* 
                      int prescaled) {
     if ((ldq | ldk | ldv | ldo) % 8 != 0) { set_error("attention: row strides must be multiples of 8"); return 1; }
     if (Tk <= 0 || Tq <= 0) return 0;
-    // FAST: whether the accumulator-start form pays for this head dim (measured: -12 % at d = 40,
-    // -7 % at d = 80, +1.5 % at d = 64 where the loop is less VALU-bound); otherwise pre-scaled
-    // queries run the general kernel with a unit scale
+    // FAST: whether the accumulator-start form pays for this head dim (measured with the DMA staging:
+    // -11 % at d = 40, where the loop is VALU-issue-bound; a wash or slightly worse from d = 64 up);
+    // otherwise pre-scaled queries run the general kernel with a unit scale
 #define SD_ATTN_CASE(DD, QQ, KK, FAST) \
     case DD: return (prescaled && FAST) \
         ? launch_attn<DD, QQ, KK, FAST>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, true, s) \
@@ -422,9 +451,9 @@ int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* 
         SD_ATTN_CASE(32, 2, 64, true);
         SD_ATTN_CASE(40, 4, 64, true);
         SD_ATTN_CASE(64, 2, 64, false);
-        SD_ATTN_CASE(80, 2, 64, true);
+        SD_ATTN_CASE(80, 2, 64, false);
         SD_ATTN_CASE(128, 2, 64, false);
-        SD_ATTN_CASE(160, 2, 64, true);
+        SD_ATTN_CASE(160, 2, 64, false);
         SD_ATTN_CASE(512, 1, 64, false);
         default:
             set_error("attention: unsupported head dim " + std::to_string(d));
