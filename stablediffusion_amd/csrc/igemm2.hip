@@ -337,6 +337,267 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with the A operand kept in LDS across the nine taps.
+//
+// igemm2_kernel gathers a fresh [BM x 64] A tile per (64-channel slab, tap): nine gathers of the same
+// rows, shifted by one pixel / one image row -- 9x the L2->LDS traffic and 9x the DMA instructions of
+// what the slab needs, and FETCH_SIZE shows those re-reads leaking past the 4 MB L2 (218 MB per
+// launch against 52 MB algorithmic on the 64x64-latent convs).  Here a block's 256 output pixels are
+// R = 256 / W whole image rows; per slab ONE halo tile [(R + 2) x (W + 2) pixels x 64 channels] is
+// DMA'd (image borders read out of range and land as zeros), double-buffered, and the nine taps read
+// it at shifted pixel offsets; only the weights [160 x 64 per tap] still stream, through a 3-deep
+// ring.  The XOR swizzle is on the halo pixel index, so the 16 consecutive pixels of an MFMA operand
+// stay conflict-free at every shift.  W in {16, 32, 64} (whole rows per tile), 8 waves (4 x 2).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {     // n is wave-uniform
+    switch (n) {
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float* partial, int slabs_per_split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr unsigned kOOB = 0x80000000u;
+    constexpr int BM = 256, BN = 160, NW = 8, NT = 512, WAVES_N = 2;
+    constexpr int WTM = 64, WTN = 80, TM = 4, TN = 5;
+    constexpr int B_INSTR = BN / 8, B_PW = 3, B_REM = B_INSTR % NW;      // 20 = 4 waves x 3 + 4 waves x 2
+    constexpr int B_STAGE_HALVES = BN * 64, B_STAGES = 3;
+    constexpr int AJ = 7;                        // halo DMA instructions per wave, at most
+    constexpr int LDC = BN + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = p.W, Wp = W + 2, HW = p.H * p.W;
+    const int R = BM / W;
+    const int HP = (R + 2) * Wp;                 // halo pixels per slab
+    const int A_HALVES = HP * 64;
+    half_t* sA = reinterpret_cast<half_t*>(smem);            // [2][HP][64], swizzled on the pixel index
+    half_t* sB = sA + 2 * A_HALVES;                          // [3][160][64]
+    half_t* sC = reinterpret_cast<half_t*>(smem);            // epilogue staging overlays both
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int img = m0 / HW, row0 = (m0 - img * HW) / W;
+    const int nslab = p.Cin / 64;
+    const int s_begin = split * slabs_per_split;
+    int s_end = s_begin + slabs_per_split;
+    if (s_end > nslab) s_end = nslab;
+
+    const long x_bytes = (long)p.N * p.H * p.W * p.ldx * 2;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, (int)x_bytes, 0x00020000);
+    const long wrows = ((long)p.Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, (int)(wrows * p.K * 2), 0x00020000);
+
+    // ---- halo DMA slots: slot = 64 * instr + lane = 8 * halo pixel + chunk position ----
+    const int NI = (HP * 8 + 63) >> 6;
+    int a_off[AJ];          // byte offset of the source chunk at slab 0; -2: outside the image (zeros); -1: no slot
+    int a_cnt = 0;          // DMA instructions this wave issues per halo tile (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int i = wave + NW * j;
+        if (i < NI) ++a_cnt;
+        const int slot = i * 64 + lane;
+        const int hp = slot >> 3, cpos = slot & 7;
+        const int hr = hp / Wp, hc = hp - hr * Wp;
+        const int ih = row0 - 1 + hr, iw = hc - 1;
+        const bool inb = ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)W);
+        const int chunk = cpos ^ (hp & 7);
+        int off = -1;
+        if (i < NI && slot < HP * 8)
+            off = inb ? (int)((((long)img * HW + (long)ih * W + iw) * p.ldx + chunk * 8) * 2) : -2;
+        a_off[j] = off;
+    }
+    auto issueA = [&](int bufi, int slab) {
+        half_t* dst = sA + bufi * A_HALVES;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int i = wave + NW * j;
+            if (i < NI && a_off[j] != -1) {
+                const unsigned voff = a_off[j] >= 0 ? (unsigned)a_off[j] + (unsigned)(slab * 128) : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + i * 512), 16,
+                                                         voff, 0, 0, 0);
+            }
+        }
+    };
+    // ---- weight tile: 8 rows of 64 halves per DMA instruction, chunk ^ (row & 7) on the source side ----
+    const int lrow = lane >> 3;
+    const int chunkB = (lane & 7) ^ lrow;
+    const bool b_hi = wave < B_REM;                              // waves 0-3 issue 3, waves 4-7 issue 2
+    const int b_cnt = b_hi ? B_PW : B_PW - 1;
+    const int b_first = b_hi ? wave * B_PW : B_REM * B_PW + (wave - B_REM) * (B_PW - 1);
+    unsigned b_off[B_PW];
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j)
+        b_off[j] = (unsigned)((((long)(n0 + (b_first + j) * 8 + lrow)) * p.K + chunkB * 8) * 2);
+    auto issueB = [&](int stage, int g) {       // K order [Cin/64][KH][KW][64]: step g = slab * 9 + tap
+        half_t* dst = sB + stage * B_STAGE_HALVES;
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            if (j < b_cnt)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (b_first + j) * 512),
+                                                         16, b_off[j] + (unsigned)(g * 128), 0, 0, 0);
+    };
+
+    f4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int hp0[TM];                                 // halo pixel of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WTM + i * 16 + fr;
+        const int r = ml / W, c = ml - r * W;
+        hp0[i] = r * Wp + c;
+    }
+
+    int g = s_begin * 9;
+    const int g_end = s_end * 9;
+    if (g < g_end) {
+        issueA(0, s_begin);
+        issueB(0, g);
+        if (g + 1 < g_end) issueB(1, g + 1);
+    }
+    int slab = s_begin, tap = 0, kh = 0, kw = 0, abuf = 0, bslot = 0;
+    bool a_next = false;                         // halo of slab + 1 was issued at this slab's tap 0
+    for (; g < g_end; ++g) {
+        // B(g) must have landed (and at tap 0 the slab's halo, which is older).  Younger loads that may
+        // stay in flight: B(g + 1), and the next halo while it is younger than B(g) (taps 1 and 2).
+        {
+            int n = (g + 1 < g_end) ? (b_hi ? B_PW : B_PW - 1) : 0;
+            if (a_next && (tap == 1 || tap == 2)) n += a_cnt;
+            wait_vmcnt_dyn(n);
+        }
+        __builtin_amdgcn_s_barrier();
+        // (staggering the issue of waves 4-7 behind their MFMAs, which pays for igemm2's 8-wave tiles,
+        // measured 2-7 % slower here)
+        if (g + 2 < g_end) issueB(bslot >= 1 ? bslot - 1 : B_STAGES - 1, g + 2);   // (bslot + 2) % 3
+        if (tap == 0) {
+            a_next = slab + 1 < s_end;
+            if (a_next) issueA(abuf ^ 1, slab + 1);
+        }
+        const half_t* cA = sA + abuf * A_HALVES;
+        const half_t* cB = sB + bslot * B_STAGE_HALVES;
+        const int tapoff = kh * Wp + kw;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8 fa[TM], fb[TN];
+            const int ch = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int hp = hp0[i] + tapoff;
+                fa[i] = *reinterpret_cast<const h8*>(cA + hp * 64 + ((ch ^ (hp & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * WTN + j * 16 + fr;
+                fb[j] = *reinterpret_cast<const h8*>(cB + r * 64 + ((ch ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        bslot = bslot + 1 == B_STAGES ? 0 : bslot + 1;
+        if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; } }
+        if (++tap == 9) { tap = 0; ++slab; abuf ^= 1; }
+    }
+
+    // ---- split-K: raw fp32 partials, reduced by splitk_epilogue_kernel ----
+    if (partial) {
+        float* dst = partial + (long)split * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + fq * 4;
+                if (m < p.M && n < p.Cout) *reinterpret_cast<f4*>(dst + (long)m * p.Cout + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+
+    // ---- fused epilogue through LDS (as igemm2_kernel) ----
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pr = wm * WTM + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * WTN + j * 16 + fq * 4;
+            f4 v = acc[i][j];
+            if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + n0 + col);
+            if (p.rowadd && n0 + col < p.Cout)
+                v += *reinterpret_cast<const f4*>(p.rowadd + (long)img * p.rowadd_ld + n0 + col);
+            h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
+        }
+    }
+    __syncthreads();
+    constexpr int CH = BN / 8;
+    for (int idx = tid; idx < BM * CH; idx += NT) {
+        const int r = idx / CH, c = (idx - r * CH) * 8;
+        const int m = m0 + r, n = n0 + c;
+        if (m < p.M && n < p.Cout) {
+            h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
+            if (p.res) {
+                const h8 rv = *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + n) = v;
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+bool halo_supported(const IGemmParams& p) {
+    return p.KS == 3 && p.stride == 1 && p.up == 0 && p.pad == 1 && !p.geglu && !p.act && p.Cin % 64 == 0 &&
+           p.Cout % 8 == 0 && (p.W == 16 || p.W == 32 || p.W == 64) && (p.H * p.W) % 256 == 0 && p.OH == p.H &&
+           p.OW == p.W && p.K == 9 * p.Cin;
+}
+
+int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
+    const int R = 256 / p.W;
+    const size_t lds = (size_t)2 * (R + 2) * (p.W + 2) * 128 + (size_t)3 * 160 * 128;
+    static size_t attr = 0;
+    if (lds > attr) {
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const int tiles = (p.M / 256) * cdiv(p.Cout, 160);
+    const int nslab = p.Cin / 64;
+    const int per = cdiv(nslab, splits);
+    const int eff_splits = cdiv(nslab, per);
+    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, eff_splits), dim3(512), lds, s, p, eff_splits > 1 ? partial : nullptr,
+                       per);
+    SD_HIP_CHECK(hipGetLastError());
+    if (eff_splits > 1) {
+        const long total = (long)p.M * (p.Cout / 8);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p, partial, eff_splits);
+        SD_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG, int BKT>
 int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     constexpr size_t ring = (size_t)STAGES * (BM + BN) * BKT * sizeof(half_t);
@@ -382,6 +643,7 @@ int g_force_splits = 0;
 //   0: 256x128 8 waves 3 stages   1: 128x128 4 waves 2 stages   2: 128x160 4 waves 2 stages
 //   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
 //   6 / 7: 256x128 / 256x160, 8 waves, staggered DMA issue
+//   10: conv3x3_halo_kernel (256x160, A halo tile resident across the taps; 3x3 stride-1 convs, W in 16/32/64)
 //   8 / 9: 128x64 / 128x160 with a 3-deep ring: only pays on the small-M, deep-K shapes of the 8x8 and
 //          16x16 levels when their weights come cold from HBM (as they do inside a forward); with the
 //          weights cache-resident the 2-deep rings win everywhere (tools/tune_igemm.py, SD_BENCH_COLD_MB)
@@ -391,8 +653,9 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<128,160,2,2,2,%s,false,64>", "igemm2_kernel<128,64,2,2,2,%s,false,64>",
     "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
     "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
-    "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>"};
-constexpr int kNumVariants = 10;
+    "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
+    "conv3x3_halo_kernel"};
+constexpr int kNumVariants = 11;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -405,7 +668,7 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}};
+                                               {128, 64}, {128, 160}, {256, 160}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -425,12 +688,14 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
         *splits = g_force_splits > 0 ? g_force_splits : 1;
         if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6) *variant = 1;
         if (p.geglu || p.act) *splits = 1;
+        if (*variant >= 10 && !halo_supported(p)) *variant = 7;
         return;
     }
     for (const TunedEntry& e : kTuned)
         if (!p.act && e.M == p.M && e.N == p.Cout && e.K == p.K && e.ks == p.KS && e.stride == p.stride && e.up == p.up &&
             e.geglu == p.geglu) {
             *variant = e.variant; *splits = e.splits;
+            if (*variant >= 10 && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
             return;
         }
     const int nk = p.K / BK;
@@ -486,6 +751,7 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 7: return launch_v2<256, 160, 4, 2, 3, true>(p, partial, sp, s);
         case 8: return launch_v2<128, 64, 2, 2, 3>(p, partial, sp, s);
         case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
+        case 10: return launch_halo(p, partial, sp, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

@@ -72,7 +72,7 @@ def test_conv2d(engine_lib, case):
     assert rel_l2(got, ref) < 2e-3            # fp16 output rounding: ~5e-4 relative
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_conv2d_every_tile_variant(engine_lib, variant, splits):
     """Every LDS-DMA tile variant (and the split-K reduction) on a 3x3, a strided, an upsampled and a
@@ -80,7 +80,9 @@ def test_conv2d_every_tile_variant(engine_lib, variant, splits):
     engine_lib.sd_igemm_force(variant, splits)
     try:
         for case in [(2, 12, 20, 128, 320, 3, 1, 0, True), (1, 16, 16, 64, 192, 3, 2, 0, True),
-                     (1, 9, 7, 128, 72, 3, 1, 1, True), (2, 17, 5, 256, 200, 1, 1, 0, True)]:
+                     (1, 9, 7, 128, 72, 3, 1, 1, True), (2, 17, 5, 256, 200, 1, 1, 0, True),
+                     # whole-row tiles the halo kernel (variant 10) takes; other variants run them as ordinary 3x3s
+                     (2, 16, 16, 128, 200, 3, 1, 0, True), (1, 8, 32, 64, 320, 3, 1, 0, True), (1, 64, 64, 64, 72, 3, 1, 0, True)]:
             test_conv2d(engine_lib, case)
     finally:
         engine_lib.sd_igemm_force(-1, 0)

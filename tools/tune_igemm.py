@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from stablediffusion_amd import _lib, config, shapes  # noqa: E402
 
 NAMES = ["256x128s3", "128x128s2", "128x160s2", "128x64s2", "64x64s2", "256x160s3", "256x128stag", "256x160w8",
-         "128x64s3", "128x160s3"]
+         "128x64s3", "128x160s3", "halo256x160"]
 
 
 def main():
@@ -60,6 +60,8 @@ def main():
         nk = c.K // 64
         for v in range(len(NAMES)):
             if c.geglu and v not in (0, 1, 6):
+                continue
+            if v == 10 and not (c.ks == 3 and c.stride == 1 and c.up == 0 and c.W in (16, 32, 64) and (c.H * c.W) % 256 == 0):
                 continue
             for sp in (1, 2, 3, 4, 6, 8):
                 if sp > 1 and (c.geglu or nk // sp < 8):
