@@ -14,6 +14,8 @@
 //     splitk_epilogue_kernel reduces the slabs in a fixed order (deterministic) and applies
 //     bias / time-embedding row add / residual / GEGLU.
 // Tile variants (BM x BN, waves, stages) are chosen per shape by pick_variant().
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sd {
@@ -67,7 +69,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
 
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    int tm, tn;
+    if (p.mfast) {
+        const int tiles_m = gridDim.x / tiles_n;
+        tn = bid / tiles_m; tm = bid - tn * tiles_m;
+    } else {
+        tm = bid / tiles_n; tn = bid - tm * tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int nk_total = p.K / BKT;
@@ -297,6 +305,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// Tile order for the launch (IGemmParams::mfast): weights bigger than the input activations -> keep a
+// weight panel on one XCD.  SD_IGEMM_MFAST=0/1 overrides (tuning experiments).
+inline int weights_outweigh_activations(const IGemmParams& p) {
+    static const char* env = getenv("SD_IGEMM_MFAST");
+    if (env) return atoi(env);
+    const double wbytes = (double)p.Cout * p.K * 2.0;
+    const double abytes = (double)p.N * p.H * p.W * p.Cin * 2.0;
+    return wbytes > abytes ? 1 : 0;
+}
+
 // Fixed-order reduction of split-K partial slabs + the fused epilogue (bias, rowadd, residual).
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, const float* __restrict__ partial,
                                                               int splits) {
@@ -385,7 +403,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    int tm, tn;
+    if (p.mfast) {
+        const int tiles_m = gridDim.x / tiles_n;
+        tn = bid / tiles_m; tm = bid - tn * tiles_m;
+    } else {
+        tm = bid / tiles_n; tn = bid - tm * tiles_n;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int split = blockIdx.y;
     const int img = m0 / HW, row0 = (m0 - img * HW) / W;
@@ -585,7 +609,9 @@ int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s)
     const int nslab = p.Cin / 64;
     const int per = cdiv(nslab, splits);
     const int eff_splits = cdiv(nslab, per);
-    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, eff_splits), dim3(512), lds, s, p, eff_splits > 1 ? partial : nullptr,
+    IGemmParams q = p;
+    q.mfast = weights_outweigh_activations(p);
+    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, eff_splits), dim3(512), lds, s, q, eff_splits > 1 ? partial : nullptr,
                        per);
     SD_HIP_CHECK(hipGetLastError());
     if (eff_splits > 1) {
@@ -614,8 +640,10 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     const int nk = p.K / BKT;
     const int per = cdiv(nk, splits);
     const int eff_splits = cdiv(nk, per);
+    IGemmParams q = p;
+    q.mfast = weights_outweigh_activations(p);
     hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
-                       p, eff_splits > 1 ? partial : nullptr, per);
+                       q, eff_splits > 1 ? partial : nullptr, per);
     SD_HIP_CHECK(hipGetLastError());
     if (eff_splits > 1) {
         const long total = (long)p.M * (p.Cout / 8);

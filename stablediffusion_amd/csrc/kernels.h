@@ -24,6 +24,11 @@ struct IGemmParams {
     int KS, stride, pad, up;
     int M, K;
     int geglu;              // 1: y[m, j] = hidden_j * gelu(gate_j), weights interleaved per 64
+    // Block -> tile order.  Each XCD (own 4 MB L2) works through a contiguous range of block ids; 0: the
+    // N tiles of one M tile are neighbours (the activation rows are fetched into one L2, every L2 pulls
+    // all the weights), 1: the M tiles of one N tile are neighbours (each weight panel goes to one L2,
+    // the activations to all).  Set by the launcher: 1 when the weights outweigh the activations.
+    int mfast = 0;
     int act = 0;            // activation after bias, before residual (LDS-DMA kernels, no split-K):
                             // 0 none, 1 quick_gelu x*sigmoid(1.702x) (CLIP-L MLP), 2 exact-erf gelu (OpenCLIP MLP)
 };
