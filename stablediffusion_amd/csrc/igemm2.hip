@@ -362,12 +362,21 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, con
 // rows, shifted by one pixel / one image row -- 9x the L2->LDS traffic and 9x the DMA instructions of
 // what the slab needs, and FETCH_SIZE shows those re-reads leaking past the 4 MB L2 (218 MB per
 // launch against 52 MB algorithmic on the 64x64-latent convs).  Here a block's 256 output pixels are
-// R = 256 / W whole image rows; per slab ONE halo tile [(R + 2) x (W + 2) pixels x 64 channels] is
+// an R x Wt patch of one image; per slab ONE halo tile [(R + 2) x (Wt + 2) pixels x 64 channels] is
 // DMA'd (image borders read out of range and land as zeros), double-buffered, and the nine taps read
 // it at shifted pixel offsets; only the weights [160 x 64 per tap] still stream, through a 3-deep
 // ring.  The XOR swizzle is on the halo pixel index, so the 16 consecutive pixels of an MFMA operand
-// stay conflict-free at every shift.  W in {16, 32, 64} (whole rows per tile), 8 waves (4 x 2).
+// stay conflict-free at every shift.  The 256 pixels are an R x Wt patch (64 / 32 / 16 columns wide,
+// whichever tiles the image), so any H x W that such a patch divides qualifies; 8 waves (4 x 2).
 // ---------------------------------------------------------------------------------------------
+// Width of the 256-pixel patch a block covers: the widest of 64 / 32 / 16 columns that tiles the image
+// (W % Wt == 0 and H % (256 / Wt) == 0); 0 if none does.
+__host__ __device__ inline int halo_patch_width(int H, int W) {
+    for (int wt = 64; wt >= 16; wt >>= 1)
+        if (W % wt == 0 && H % (256 / wt) == 0) return wt;
+    return 0;
+}
+
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {     // n is wave-uniform
     switch (n) {
         case 2: wait_vmcnt<2>(); break;
@@ -390,8 +399,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     constexpr int AJ = 7;                        // halo DMA instructions per wave, at most
     constexpr int LDC = BN + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int W = p.W, Wp = W + 2, HW = p.H * p.W;
-    const int R = BM / W;
+    // tile = an R x Wt patch of one image (Wt = the widest of 64 / 32 / 16 that divides W, R = 256 / Wt)
+    const int W = p.W, HW = p.H * p.W;
+    const int Wt = halo_patch_width(p.H, W), Wp = Wt + 2;
+    const int R = BM / Wt;
     const int HP = (R + 2) * Wp;                 // halo pixels per slab
     const int A_HALVES = HP * 64;
     half_t* sA = reinterpret_cast<half_t*>(smem);            // [2][HP][64], swizzled on the pixel index
@@ -410,9 +421,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     } else {
         tm = bid / tiles_n; tn = bid - tm * tiles_n;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int n0 = tn * BN;
     const int split = blockIdx.y;
-    const int img = m0 / HW, row0 = (m0 - img * HW) / W;
+    const int patches_w = W / Wt, patches = (p.H / R) * patches_w;
+    const int img = tm / patches, pidx = tm - img * patches;
+    const int row0 = (pidx / patches_w) * R, col0 = (pidx % patches_w) * Wt;
+    // GEMM row (NHWC pixel index) of the tile's local pixel ml
+    auto row_of = [&](int ml) { const int r = ml / Wt; return img * HW + (row0 + r) * W + col0 + (ml - r * Wt); };
     const int nslab = p.Cin / 64;
     const int s_begin = split * slabs_per_split;
     int s_end = s_begin + slabs_per_split;
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         const int slot = i * 64 + lane;
         const int hp = slot >> 3, cpos = slot & 7;
         const int hr = hp / Wp, hc = hp - hr * Wp;
-        const int ih = row0 - 1 + hr, iw = hc - 1;
+        const int ih = row0 - 1 + hr, iw = col0 - 1 + hc;
         const bool inb = ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)W);
         const int chunk = cpos ^ (hp & 7);
         int off = -1;
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm * WTM + i * 16 + fr;
-        const int r = ml / W, c = ml - r * W;
+        const int r = ml / Wt, c = ml - r * Wt;
         hp0[i] = r * Wp + c;
     }
 
@@ -546,11 +561,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         float* dst = partial + (long)split * p.M * p.Cout;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + fr;
+            const int m = row_of(wm * WTM + i * 16 + fr);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 16 + fq * 4;
-                if (m < p.M && n < p.Cout) *reinterpret_cast<f4*>(dst + (long)m * p.Cout + n) = acc[i][j];
+                if (n < p.Cout) *reinterpret_cast<f4*>(dst + (long)m * p.Cout + n) = acc[i][j];
             }
         }
         return;
@@ -576,8 +591,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     constexpr int CH = BN / 8;
     for (int idx = tid; idx < BM * CH; idx += NT) {
         const int r = idx / CH, c = (idx - r * CH) * 8;
-        const int m = m0 + r, n = n0 + c;
-        if (m < p.M && n < p.Cout) {
+        const int m = row_of(r), n = n0 + c;
+        if (n < p.Cout) {
             h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
             if (p.res) {
                 const h8 rv = *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n);
@@ -592,13 +607,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
 
 bool halo_supported(const IGemmParams& p) {
     return p.KS == 3 && p.stride == 1 && p.up == 0 && p.pad == 1 && !p.geglu && !p.act && p.Cin % 64 == 0 &&
-           p.Cout % 8 == 0 && (p.W == 16 || p.W == 32 || p.W == 64) && (p.H * p.W) % 256 == 0 && p.OH == p.H &&
-           p.OW == p.W && p.K == 9 * p.Cin;
+           p.Cout % 8 == 0 && halo_patch_width(p.H, p.W) > 0 && p.OH == p.H && p.OW == p.W && p.K == 9 * p.Cin;
 }
 
 int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
-    const int R = 256 / p.W;
-    const size_t lds = (size_t)2 * (R + 2) * (p.W + 2) * 128 + (size_t)3 * 160 * 128;
+    const int Wt = halo_patch_width(p.H, p.W), R = 256 / Wt;
+    const size_t lds = (size_t)2 * (R + 2) * (Wt + 2) * 128 + (size_t)3 * 160 * 128;
     static size_t attr = 0;
     if (lds > attr) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),

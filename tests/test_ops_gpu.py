@@ -81,8 +81,9 @@ def test_conv2d_every_tile_variant(engine_lib, variant, splits):
     try:
         for case in [(2, 12, 20, 128, 320, 3, 1, 0, True), (1, 16, 16, 64, 192, 3, 2, 0, True),
                      (1, 9, 7, 128, 72, 3, 1, 1, True), (2, 17, 5, 256, 200, 1, 1, 0, True),
-                     # whole-row tiles the halo kernel (variant 10) takes; other variants run them as ordinary 3x3s
-                     (2, 16, 16, 128, 200, 3, 1, 0, True), (1, 8, 32, 64, 320, 3, 1, 0, True), (1, 64, 64, 64, 72, 3, 1, 0, True)]:
+                     # shapes a 256-pixel patch tiles: the halo kernel (variant 10) takes them, the others run them as ordinary 3x3s
+                     (2, 16, 16, 128, 200, 3, 1, 0, True), (1, 8, 32, 64, 320, 3, 1, 0, True), (1, 64, 64, 64, 72, 3, 1, 0, True),
+                     (1, 32, 48, 64, 72, 3, 1, 0, True), (1, 8, 128, 128, 160, 3, 1, 0, True)]:   # 16- and 64-wide patches
             test_conv2d(engine_lib, case)
     finally:
         engine_lib.sd_igemm_force(-1, 0)

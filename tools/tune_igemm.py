@@ -61,7 +61,8 @@ def main():
         for v in range(len(NAMES)):
             if c.geglu and v not in (0, 1, 6):
                 continue
-            if v == 10 and not (c.ks == 3 and c.stride == 1 and c.up == 0 and c.W in (16, 32, 64) and (c.H * c.W) % 256 == 0):
+            if v == 10 and not (c.ks == 3 and c.stride == 1 and c.up == 0 and
+                                any(c.W % wt == 0 and c.H % (256 // wt) == 0 for wt in (64, 32, 16))):
                 continue
             for sp in (1, 2, 3, 4, 6, 8):
                 if sp > 1 and (c.geglu or nk // sp < 8):
