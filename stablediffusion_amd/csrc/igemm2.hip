@@ -377,18 +377,6 @@ __host__ __device__ inline int halo_patch_width(int H, int W) {
     return 0;
 }
 
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {     // n is wave-uniform
-    switch (n) {
-        case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;
-        case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;
-        default: wait_vmcnt<0>(); break;
-    }
-}
-
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float* partial, int slabs_per_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr unsigned kOOB = 0x80000000u;
@@ -441,11 +429,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     // ---- halo DMA slots: slot = 64 * instr + lane = 8 * halo pixel + chunk position ----
     const int NI = (HP * 8 + 63) >> 6;
     int a_off[AJ];          // byte offset of the source chunk at slab 0; -2: outside the image (zeros); -1: no slot
-    int a_cnt = 0;          // DMA instructions this wave issues per halo tile (wave-uniform)
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int i = wave + NW * j;
-        if (i < NI) ++a_cnt;
         const int slot = i * 64 + lane;
         const int hp = slot >> 3, cpos = slot & 7;
         const int hr = hp / Wp, hc = hp - hr * Wp;
@@ -515,14 +501,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     for (; g < g_end; ++g) {
         // B(g) must have landed (and at tap 0 the slab's halo, which is older).  Younger loads that may
         // stay in flight: B(g + 1), and the next halo while it is younger than B(g) (taps 1 and 2).
-        {
-            int n = (g + 1 < g_end) ? (b_hi ? B_PW : B_PW - 1) : 0;
-            if (a_next && (tap == 1 || tap == 2)) n += a_cnt;
-            wait_vmcnt_dyn(n);
-        }
+        // (immediates: the smallest share any wave has -- 2 weight instructions, 5 halo instructions)
+        if (g + 1 >= g_end) wait_vmcnt<0>();
+        else if (a_next && (tap == 1 || tap == 2)) wait_vmcnt<7>();
+        else wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
-        // (staggering the issue of waves 4-7 behind their MFMAs, which pays for igemm2's 8-wave tiles,
-        // measured 2-7 % slower here)
+        // (measured and dropped: staggering the issue of waves 4-7 behind their MFMAs, 2-7 % slower; a
+        // two-phase ping-pong -- fragments of both k-steps into registers | 40 MFMAs, the SIMD partners
+        // half a step apart, two barriers per step -- ties this loop; unrolling the nine taps, 15 % slower.
+        // Ablation of this loop at 64x64x320: 0.26 us of a 1.29 us step is barrier + scalar control with
+        // an empty body, 0.65 us the MFMAs at full rate, 0.44 us the LDS / DMA side on its own.)
         if (g + 2 < g_end) issueB(bslot >= 1 ? bslot - 1 : B_STAGES - 1, g + 2);   // (bslot + 2) % 3
         if (tap == 0) {
             a_next = slab + 1 < s_end;
