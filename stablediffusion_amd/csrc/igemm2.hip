@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     constexpr int BM = 256, BN = 160, NW = 8, NT = 512, WAVES_N = 2;
     constexpr int WTM = 64, WTN = 80, TM = 4, TN = 5;
     constexpr int B_INSTR = BN / 8, B_PW = 3, B_REM = B_INSTR % NW;      // 20 = 4 waves x 3 + 4 waves x 2
-    constexpr int B_STAGE_HALVES = BN * 64, B_STAGES = 3;
+    constexpr int B_STAGE_HALVES = BN * 64;     // three ring stages: one per tap of a kernel row
     constexpr int AJ = 7;                        // halo DMA instructions per wave, at most
     constexpr int LDC = BN + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -496,52 +496,55 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         issueB(0, g);
         if (g + 1 < g_end) issueB(1, g + 1);
     }
-    int slab = s_begin, tap = 0, kh = 0, kw = 0, abuf = 0, bslot = 0;
-    bool a_next = false;                         // halo of slab + 1 was issued at this slab's tap 0
-    for (; g < g_end; ++g) {
-        // B(g) must have landed (and at tap 0 the slab's halo, which is older).  Younger loads that may
-        // stay in flight: B(g + 1), and the next halo while it is younger than B(g) (taps 1 and 2).
-        // (immediates: the smallest share any wave has -- 2 weight instructions, 5 halo instructions)
-        if (g + 1 >= g_end) wait_vmcnt<0>();
-        else if (a_next && (tap == 1 || tap == 2)) wait_vmcnt<7>();
-        else wait_vmcnt<2>();
-        __builtin_amdgcn_s_barrier();
-        // (measured and dropped: staggering the issue of waves 4-7 behind their MFMAs, 2-7 % slower; a
-        // two-phase ping-pong -- fragments of both k-steps into registers | 40 MFMAs, the SIMD partners
-        // half a step apart, two barriers per step -- ties this loop; unrolling the nine taps, 15 % slower.
-        // Ablation of this loop at 64x64x320: 0.26 us of a 1.29 us step is barrier + scalar control with
-        // an empty body, 0.65 us the MFMAs at full rate, 0.44 us the LDS / DMA side on its own.)
-        if (g + 2 < g_end) issueB(bslot >= 1 ? bslot - 1 : B_STAGES - 1, g + 2);   // (bslot + 2) % 3
-        if (tap == 0) {
-            a_next = slab + 1 < s_end;
-            if (a_next) issueA(abuf ^ 1, slab + 1);
-        }
+    // Main loop: slab -> kernel row -> the three taps of the row, unrolled.  The weight ring has three
+    // stages, so the stage of a tap is its kw: compile-time, like the waits' immediates (the smallest
+    // share any wave has: 2 weight instructions, 5 halo instructions).
+    int abuf = 0;
+    bool a_next = false;                         // halo of slab + 1 was issued at this slab's first tap
+    for (int slab = s_begin; slab < s_end; ++slab) {
+        const bool lastslab = slab + 1 >= s_end;
         const half_t* cA = sA + abuf * A_HALVES;
-        const half_t* cB = sB + bslot * B_STAGE_HALVES;
-        const int tapoff = kh * Wp + kw;
+        for (int kh = 0; kh < 3; ++kh) {
+            const bool lastrow = lastslab && kh == 2;
+            const int rowoff = kh * Wp;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 fa[TM], fb[TN];
-            const int ch = ks * 4 + fq;
+            for (int kw = 0; kw < 3; ++kw, ++g) {
+                // B(g) must have landed (and at the first tap the slab's halo, which is older).  Younger loads
+                // that may stay in flight: B(g + 1), and the next halo while it is younger than B(g) (taps 1, 2).
+                if (lastrow && kw == 2) wait_vmcnt<0>();
+                else if (a_next && kh == 0 && kw >= 1) wait_vmcnt<7>();
+                else wait_vmcnt<2>();
+                __builtin_amdgcn_s_barrier();
+                if (!(lastrow && kw >= 1)) issueB((kw + 2) % 3, g + 2);
+                if (kw == 0 && kh == 0) {
+                    a_next = !lastslab;
+                    if (a_next) issueA(abuf ^ 1, slab + 1);
+                }
+                const half_t* cB = sB + kw * B_STAGE_HALVES;
+                const int tapoff = rowoff + kw;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int hp = hp0[i] + tapoff;
-                fa[i] = *reinterpret_cast<const h8*>(cA + hp * 64 + ((ch ^ (hp & 7)) << 3));
+                for (int ks = 0; ks < 2; ++ks) {
+                    h8 fa[TM], fb[TN];
+                    const int ch = ks * 4 + fq;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int hp = hp0[i] + tapoff;
+                        fa[i] = *reinterpret_cast<const h8*>(cA + hp * 64 + ((ch ^ (hp & 7)) << 3));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int r = wn * WTN + j * 16 + fr;
+                        fb[j] = *reinterpret_cast<const h8*>(cB + r * 64 + ((ch ^ (r & 7)) << 3));
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = wn * WTN + j * 16 + fr;
-                fb[j] = *reinterpret_cast<const h8*>(cB + r * 64 + ((ch ^ (r & 7)) << 3));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        bslot = bslot + 1 == B_STAGES ? 0 : bslot + 1;
-        if (++kw == 3) { kw = 0; if (++kh == 3) { kh = 0; } }
-        if (++tap == 9) { tap = 0; ++slab; abuf ^= 1; }
+        abuf ^= 1;
     }
 
     // ---- split-K: raw fp32 partials, reduced by splitk_epilogue_kernel ----
