@@ -182,49 +182,54 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
         if (s < nk) issue(s);
 
     const int fr = lane & 15, fq = lane >> 4;
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt must have landed; at most D-1 younger stages may stay in flight
-        {
-            const int rem = nk - 1 - kt;
-            if (D >= 3 && rem >= 2) {
-                if (b_hi) wait_vmcnt<2 * LPW>(); else wait_vmcnt<2 * LPW_LO>();
-            } else if (D >= 2 && rem >= 1) {
-                if (b_hi) wait_vmcnt<LPW>(); else wait_vmcnt<LPW_LO>();
-            } else {
-                wait_vmcnt<0>();
+    // The K loop is unrolled by the ring depth, so a step's ring slot (and the slot its DMA refills) is
+    // compile-time; a step's scalar work is the wait, the barrier and the issue's address updates.
+    for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+        for (int slot = 0; slot < STAGES; ++slot) {
+            const int kt = kt0 + slot;
+            if (kt >= nk) break;
+            // stage kt must have landed; at most D-1 younger stages may stay in flight
+            {
+                const int rem = nk - 1 - kt;
+                if (D >= 3 && rem >= 2) {
+                    if (b_hi) wait_vmcnt<2 * LPW>(); else wait_vmcnt<2 * LPW_LO>();
+                } else if (D >= 2 && rem >= 1) {
+                    if (b_hi) wait_vmcnt<LPW>(); else wait_vmcnt<LPW_LO>();
+                } else {
+                    wait_vmcnt<0>();
+                }
             }
+            __builtin_amdgcn_s_barrier();
+            // (kt + D) % STAGES == (kt - 1) % STAGES.  With STAG the second wave group (the SIMD partners
+            // of waves 0-3) issues its DMA after its MFMAs instead of before them, so on every SIMD one
+            // wave is in its address/DMA-issue phase while the other feeds the matrix pipe.
+            const bool late = STAG && wave >= NW / 2;
+            if (!late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
+            const half_t* cA = ring + slot * STAGE_HALVES;
+            const half_t* cB = cA + BM * BKT;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                h8 fa[TM], fb[TN];
+                const int ch = ks * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * WTM + i * 16 + fr;
+                    fa[i] = *reinterpret_cast<const h8*>(cA + r * BKT + ((ch ^ swz(r)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wn * WTN + j * 16 + fr;
+                    fb[j] = *reinterpret_cast<const h8*>(cB + r * BKT + ((ch ^ swz(r)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            if (late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
         }
-        __builtin_amdgcn_s_barrier();
-        // (kt + D) % STAGES == (kt - 1) % STAGES.  With STAG the second wave group (the SIMD partners
-        // of waves 0-3) issues its DMA after its MFMAs instead of before them, so on every SIMD one
-        // wave is in its address/DMA-issue phase while the other feeds the matrix pipe.
-        const bool late = STAG && wave >= NW / 2;
-        if (!late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
-        const half_t* cA = ring + slot * STAGE_HALVES;
-        const half_t* cB = cA + BM * BKT;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            h8 fa[TM], fb[TN];
-            const int ch = ks * 4 + fq;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = wm * WTM + i * 16 + fr;
-                fa[i] = *reinterpret_cast<const h8*>(cA + r * BKT + ((ch ^ swz(r)) << 3));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = wn * WTN + j * 16 + fr;
-                fb[j] = *reinterpret_cast<const h8*>(cB + r * BKT + ((ch ^ swz(r)) << 3));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        if (late && kt + D < nk) issue(slot == 0 ? STAGES - 1 : slot - 1);
-        slot = (slot + 1 == STAGES) ? 0 : slot + 1;
     }
 
     // ---- split-K: raw fp32 partials, reduced by splitk_epilogue_kernel ----
