@@ -37,6 +37,9 @@ def short(k):
     m = re.search(r"N_1\d\d?([a-z_0-9]+?_kernel)(ILi(\d+))?", k)
     if m:
         return m.group(1) + (f"<{m.group(3)}>" if m.group(3) else "")
+    m = re.search(r"(\w+_kernel)\(", k)          # demangled, non-template: sd::(anonymous namespace)::name(args)
+    if m:
+        return m.group(1)
     return k[:60]
 
 
