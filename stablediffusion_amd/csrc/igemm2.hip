@@ -247,21 +247,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
         return;
     }
 
-    // ---- fused epilogue through LDS (same as igemm.hip) ----
+    // ---- fused epilogue through LDS (same as igemm.hip).  Every global load of the epilogue is issued
+    //      in a batch ahead of its first use: one load-and-wait per accumulator tile (bias, row add) and
+    //      per output chunk (residual) serialises 20-30 L2 round trips per block otherwise. ----
     __syncthreads();     // every wave is done with the ring before it is overlaid
+    f4 bias4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        bias4[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pr = wm * WTM + i * 16 + fr;
         const int m = m0 + pr;
-        int nimg = 0;
-        if (p.rowadd) nimg = (m < p.M ? m : 0) / OHW;
+        f4 add[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) add[j] = bias4[j];
+        if (p.rowadd) {
+            const float* ra = p.rowadd + (long)((m < p.M ? m : 0) / OHW) * p.rowadd_ld + n0 + wn * WTN + fq * 4;
+            f4 r4[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                r4[j] = n0 + wn * WTN + j * 16 + fq * 4 < p.Cout ? *reinterpret_cast<const f4*>(ra + j * 16) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) add[j] += r4[j];
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * WTN + j * 16 + fq * 4;
-            f4 v = acc[i][j];
-            if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + n0 + col);
-            if (p.rowadd && n0 + col < p.Cout)
-                v += *reinterpret_cast<const f4*>(p.rowadd + (long)nimg * p.rowadd_ld + n0 + col);
+            f4 v = acc[i][j] + add[j];
             if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
@@ -294,15 +307,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
         return;
     }
     constexpr int CH = BN / 8;
-    for (int idx = tid; idx < BM * CH; idx += NT) {
+    constexpr int ITER = BM * CH / NT;
+    static_assert(BM * CH % NT == 0, "output chunks must divide over the threads");
+    h8 rv[ITER];
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NT;
+            const int r = idx / CH, c = (idx - r * CH) * 8;
+            const int m = m0 + r, n = n0 + c;
+            rv[it] = (m < p.M && n < p.Cout) ? *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n)
+                                             : h8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * NT;
         const int r = idx / CH, c = (idx - r * CH) * 8;
         const int m = m0 + r, n = n0 + c;
         if (m < p.M && n < p.Cout) {
             h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
             if (p.res) {
-                const h8 rv = *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[it][e]);
             }
             *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + n) = v;
         }
@@ -567,33 +594,57 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         return;
     }
 
-    // ---- fused epilogue through LDS (as igemm2_kernel) ----
+    // ---- fused epilogue through LDS (as igemm2_kernel: loads batched ahead of their use) ----
     __syncthreads();
+    {
+        f4 add[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int pr = wm * WTM + i * 16 + fr;
+        for (int j = 0; j < TN; ++j)
+            add[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        if (p.rowadd) {          // one image per tile: the row add is the same for every row
+            const float* ra = p.rowadd + (long)img * p.rowadd_ld + n0 + wn * WTN + fq * 4;
+            f4 r4[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = wn * WTN + j * 16 + fq * 4;
-            f4 v = acc[i][j];
-            if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + n0 + col);
-            if (p.rowadd && n0 + col < p.Cout)
-                v += *reinterpret_cast<const f4*>(p.rowadd + (long)img * p.rowadd_ld + n0 + col);
-            h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
+            for (int j = 0; j < TN; ++j)
+                r4[j] = n0 + wn * WTN + j * 16 + fq * 4 < p.Cout ? *reinterpret_cast<const f4*>(ra + j * 16) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) add[j] += r4[j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int pr = wm * WTM + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WTN + j * 16 + fq * 4;
+                const f4 v = acc[i][j] + add[j];
+                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
+            }
         }
     }
     __syncthreads();
     constexpr int CH = BN / 8;
-    for (int idx = tid; idx < BM * CH; idx += NT) {
+    constexpr int ITER = BM * CH / NT;
+    h8 rv[ITER];
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NT;
+            const int r = idx / CH, c = (idx - r * CH) * 8;
+            rv[it] = n0 + c < p.Cout ? *reinterpret_cast<const h8*>(p.res + (long)row_of(r) * p.ldres + n0 + c)
+                                     : h8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * NT;
         const int r = idx / CH, c = (idx - r * CH) * 8;
         const int m = row_of(r), n = n0 + c;
         if (n < p.Cout) {
             h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
             if (p.res) {
-                const h8 rv = *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[it][e]);
             }
             *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + n) = v;
         }
