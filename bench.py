@@ -24,15 +24,21 @@ import re
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stablediffusion_amd import _lib, config, distributed as sdd, weights  # noqa: E402
-from stablediffusion_amd.models import HipAutoencoderKL, HipUNet2DConditionModel  # noqa: E402
-from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline  # noqa: E402
-from stablediffusion_amd.schedulers import DDIMScheduler  # noqa: E402
+
+def _imports():
+    """Project imports happen in the worker ranks only: the launcher parent (`--gpus N` without a
+    torchrun environment) must never touch the GPU, it only starts the ranks and relays rank 0."""
+    global torch, _lib, config, sdd, weights, HipAutoencoderKL, HipUNet2DConditionModel
+    global SDModelWrapper, StableDiffusionUnifiedPipeline, DDIMScheduler
+    import torch
+    from stablediffusion_amd import _lib, config, distributed as sdd, weights
+    from stablediffusion_amd.models import HipAutoencoderKL, HipUNet2DConditionModel
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md:43
 HBM_PEAK_GBS = 8000.0       # spec; 6.29 TB/s achievable (MI355X_MICROARCH.md:36)
@@ -163,6 +169,70 @@ def cpu_baseline(ucfg, vcfg, usd, vsd, steps, lat_hw, ehs_len):
     }
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N fresh worker processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay rank 0's JSON line, and return non-zero if
+    any rank fails.  The parent never initialises the GPU (`torch.cuda.device_count()` does not, on
+    this image) and never replaces a GPU process; it refuses when fewer than N devices are visible
+    unless SD_DIST_BACKEND=gloo asks for a rehearsal with several ranks per device."""
+    import subprocess
+    rehearse = "--rehearse" in argv
+    if not rehearse and os.environ.get("SD_DIST_BACKEND") != "gloo":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            log(f"[bench] --gpus {n} requested but only {have} GPU(s) visible: refusing to run "
+                f"(set SD_DIST_BACKEND=gloo to rehearse {n} ranks on fewer devices)")
+            return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=300))
+        except subprocess.TimeoutExpired:      # rank 0 is gone: a straggler can only be stuck
+            p.kill()
+            rcs.append(p.wait())
+    if any(rcs):
+        log(f"[bench] rank exit codes {rcs}: failing")
+        if out0:
+            log(out0)
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+def rehearse_ranks():
+    """--rehearse: the ranks only rendezvous over gloo and count each other (no GPU, no engine):
+    covers the launcher, the environment plumbing and the relay on a CPU-only box."""
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    import torch
+    t = torch.tensor([1.0])
+    dist.all_reduce(t)
+    dist.barrier()
+    if os.environ.get("SD_BENCH_REHEARSE_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": dist.get_world_size(), "ranks_counted": int(t.item())}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,12 +251,23 @@ def main():
     ap.add_argument("--no-large", action="store_true",
                     help="skip the extra 4x128x128-latent (1024 px) pass reported under `extra`")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="ranks only rendezvous over gloo and count each other (launcher self-test, no GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.rehearse:
+        return rehearse_ranks()
+    _imports()
+    if sdd.env_world()[2] != args.gpus:
+        world = sdd.env_world()[2]
+        # under torchrun the environment is the truth; a mismatch is a mis-launch, not a fallback
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a mislabelled run")
+        sys.exit(2)
     rank, world = sdd.init()
-    if world != args.gpus and world > 1:
-        log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
-    n_gpus = max(world, 1)
+    n_gpus = sdd.world_size()       # the number of ranks the collectives really see
+    assert n_gpus == world, (n_gpus, world)
     _lib.require_gpu()
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)

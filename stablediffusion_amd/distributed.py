@@ -39,6 +39,11 @@ def init(backend: Optional[str] = None) -> Tuple[int, int]:
     return rank, world
 
 
+def world_size() -> int:
+    """Number of ranks the collectives see (1 when torch.distributed is not initialised)."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous split; ranks < total % world get one extra sample."""
     base, rem = divmod(total, world)

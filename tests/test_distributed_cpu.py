@@ -72,3 +72,40 @@ def test_shard_bounds():
     assert [sdd.shard_bounds(32, r, 8) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
     assert [sdd.shard_bounds(5, r, 2) for r in range(2)] == [(0, 3), (3, 5)]
     assert [sdd.shard_bounds(1, r, 2) for r in range(2)] == [(0, 1), (1, 1)]
+
+
+# ---- bench.py launcher: `python bench.py --gpus N` must itself produce N ranks ----
+
+def _bench(*argv, **env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True,
+                       text=True, timeout=240)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_launcher_spawns_n_ranks():
+    rc, js, err = _bench("--gpus", "2", "--rehearse")
+    assert rc == 0, err
+    assert js == {"rehearsal": True, "n_gpus": 2, "ranks_counted": 2}
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    rc, js, err = _bench("--gpus", "2", "--rehearse", SD_BENCH_REHEARSE_FAIL_RANK="1")
+    assert rc != 0 and "rank exit codes" in err
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
+def test_bench_refuses_more_gpus_than_visible():
+    rc, js, err = _bench("--gpus", "2")
+    assert rc != 0 and js is None and "refusing" in err
+
+
+def test_bench_refuses_mislabelled_world():
+    rc, js, err = _bench("--gpus", "4", WORLD_SIZE="2", RANK="0", MASTER_PORT="1")
+    assert rc != 0 and js is None and "mislabelled" in err
