@@ -87,6 +87,11 @@ class DPMpp2MRef:
     def scale_model_input(self, x, t):
         return x
 
+    def start_at(self, t):
+        """Loop entered mid-schedule (img2img strength < 1 / denoising_start): diffusers resolves the
+        step index from the first timestep it is given (`_init_step_index`)."""
+        self.i = int(np.nonzero(self.timesteps == int(t))[0][0])
+
     @staticmethod
     def _alpha_sigma(s):
         a = 1.0 / np.sqrt(s * s + 1.0)
@@ -139,6 +144,10 @@ class EulerRef:
         self.init_noise_sigma = float(np.sqrt(self.sigmas.max() ** 2 + 1.0))
         self.i = 0
         return ts
+
+    def start_at(self, t):
+        """See DPMpp2MRef.start_at."""
+        self.i = int(np.nonzero(np.isclose(self.timesteps, float(t)))[0][0])
 
     def scale_model_input(self, x, t):
         s = self.sigmas[self.i]

@@ -60,6 +60,26 @@ class _Base:
     def scale_model_input(self, sample, timestep=None):
         return sample
 
+    def _begin(self, timestep):
+        """Position in the sigma schedule of the step being taken.  The first call after
+        set_timesteps resolves it from the timestep (diffusers `_init_step_index` /
+        `index_for_timestep`: with duplicates the second match, so that a loop started mid-schedule
+        -- img2img with strength < 1, denoising_start; sd_unified_pipeline.py:722-761 slices
+        `timesteps[t_start * order:]` -- does not skip a sigma); later calls just count."""
+        if self._i is None:
+            if timestep is None:
+                self._i = 0
+            else:
+                ts = self.timesteps.double().cpu().numpy()
+                hit = np.nonzero(np.isclose(ts, float(timestep)))[0]
+                if len(hit) == 0:
+                    raise ValueError(f"timestep {float(timestep)} is not in the schedule set by set_timesteps")
+                self._i = int(hit[1] if len(hit) > 1 else hit[0])
+        return self._i
+
+    def set_begin_index(self, begin_index=0):
+        self._i = int(begin_index)
+
     def add_noise_coefficients(self, timestep):
         """(a, b) of add_noise(x0, noise, t) = a x0 + b noise for one timestep (host floats)."""
         t = int(timestep)
@@ -128,7 +148,7 @@ class DPMSolverMultistepScheduler(_Base):
         self.sigmas = np.concatenate([sig, [0.0]])
         self.num_inference_steps = n
         self.timesteps = torch.from_numpy(ts).to(device)
-        self._i = 0
+        self._i = None
         self._m_prev = None
         self._fused_hist = False
 
@@ -139,7 +159,7 @@ class DPMSolverMultistepScheduler(_Base):
 
     def fused_plan(self, timestep=None):
         """The arithmetic of `step` below, collected into coefficients of (x, eps, previous x0)."""
-        i, n = self._i, self.num_inference_steps
+        i, n = self._begin(timestep), self.num_inference_steps
         a0, sg0 = self._alpha_sigma(self.sigmas[i])
         a_t, sg_t = self._alpha_sigma(self.sigmas[i + 1])
         lam0 = np.log(a0) - np.log(sg0)
@@ -147,7 +167,7 @@ class DPMSolverMultistepScheduler(_Base):
         h = lam_t - lam0
         em1 = float(np.exp(-h) - 1.0)
         h_x, h_eps = 1.0 / a0, -sg0 / a0
-        first_order = i == 0 or i == n - 1 or not getattr(self, "_fused_hist", False)
+        first_order = i == n - 1 or not getattr(self, "_fused_hist", False)
         b, c_hist = -a_t * em1, 0.0
         if not first_order:
             a1, sg1 = self._alpha_sigma(self.sigmas[i - 1])
@@ -162,7 +182,7 @@ class DPMSolverMultistepScheduler(_Base):
         self._i += 1
 
     def step(self, model_output, timestep, sample, return_dict=False, **kw):
-        i = self._i
+        i = self._begin(timestep)
         n = self.num_inference_steps
         a0, sg0 = self._alpha_sigma(self.sigmas[i])
         a_t, sg_t = self._alpha_sigma(self.sigmas[i + 1])
@@ -172,7 +192,7 @@ class DPMSolverMultistepScheduler(_Base):
         lam_t = np.log(a_t) - np.log(sg_t) if sg_t > 0 else np.inf
         h = lam_t - lam0
         em1 = float(np.exp(-h) - 1.0)
-        first_order = i == 0 or i == n - 1 or self._m_prev is None
+        first_order = i == n - 1 or self._m_prev is None
         out = float(sg_t / sg0) * x - float(a_t) * em1 * m0
         if not first_order:
             a1, sg1 = self._alpha_sigma(self.sigmas[i - 1])
@@ -202,10 +222,10 @@ class EulerDiscreteScheduler(_Base):
         self.init_noise_sigma = float((self.sigmas.max() ** 2 + 1) ** 0.5)
         self.num_inference_steps = n
         self.timesteps = torch.from_numpy(ts.astype(np.float32)).to(device)
-        self._i = 0
+        self._i = None
 
     def scale_model_input(self, sample, timestep=None):
-        s = self.sigmas[self._i]
+        s = self.sigmas[self._begin(timestep)]
         return (sample.float() / float((s * s + 1) ** 0.5)).to(sample.dtype)
 
     def add_noise_coefficients(self, timestep):
@@ -224,7 +244,8 @@ class EulerDiscreteScheduler(_Base):
         return (original.float() + s * noise.float()).to(original.dtype)
 
     def fused_plan(self, timestep=None):
-        s, s_next = self.sigmas[self._i], self.sigmas[self._i + 1]
+        i = self._begin(timestep)
+        s, s_next = self.sigmas[i], self.sigmas[i + 1]
         return FusedPlan(in_scale=float(1.0 / (s * s + 1) ** 0.5), c_x=1.0, c_eps=float(s_next - s), c_hist=0.0,
                          h_x=0.0, h_eps=0.0, use_hist=False)
 
@@ -232,7 +253,8 @@ class EulerDiscreteScheduler(_Base):
         self._i += 1
 
     def step(self, model_output, timestep, sample, return_dict=False, **kw):
-        s, s_next = self.sigmas[self._i], self.sigmas[self._i + 1]
+        i = self._begin(timestep)
+        s, s_next = self.sigmas[i], self.sigmas[i + 1]
         prev = (sample.float() + model_output.float() * float(s_next - s)).to(sample.dtype)
         self._i += 1
         return (prev,) if not return_dict else SimpleNamespace(prev_sample=prev)

@@ -137,6 +137,60 @@ def test_fused_plan_equals_step(name, n):
         assert rel_l2(xb, xa) < 1e-5, (name, t)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name,ref_cls", [("DPM++ 2M", schedulers_ref.DPMpp2MRef), ("euler", schedulers_ref.EulerRef)])
+@pytest.mark.parametrize("mode", ["strength", "denoising_start"])
+def test_mid_schedule_start_uses_the_sigma_of_its_timestep(name, ref_cls, mode, fused):
+    """img2img / inpaint with strength < 1 and denoising_start enter the loop at timesteps[t_start:]
+    (`sd_unified_pipeline.py:722-761`); the sigma-indexed schedulers must then step from sigma(t_start),
+    not sigma[0]: add_noise at sigma(t_start) followed by the loop, product scheduler
+    (generic step and fused plan) vs the oracle started at the same index."""
+    n = 10
+    kw = {"timestep_spacing": "leading"} if name == "DPM++ 2M" else {}
+    prod = schedulers.REGISTRY[name](schedulers.DDIMScheduler(**kw).config)
+    ref = ref_cls()
+    prod.set_timesteps(n)
+    ref.set_timesteps(n)
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cpu")
+    from types import SimpleNamespace
+    pipe.model = SimpleNamespace(scheduler=prod)
+    if mode == "strength":
+        ts, cnt = pipe.get_timesteps(n, 0.5)
+        assert cnt == 5
+    else:
+        ts, cnt = pipe.get_timesteps(n, 1.0, denoising_start=0.35)
+        assert 0 < cnt < n
+    assert np.allclose(ts.double().numpy(), np.asarray(ref.timesteps[-cnt:], dtype=np.float64))
+    ref.start_at(float(ts[0]))
+    assert ref.i == n - cnt
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 8, 8, generator=g).double()
+    xr = x.numpy().copy()
+    hist = torch.zeros_like(x)
+    for t in ts:
+        eps = torch.randn(2, 4, 8, 8, generator=g).double()
+        want_in = ref.scale_model_input(xr, float(t))
+        xr = ref.step(eps.numpy(), float(t), xr)
+        if fused:
+            plan = prod.fused_plan(t)
+            assert np.allclose((plan.in_scale * x).numpy(), want_in, atol=1e-5)
+            x0 = plan.h_x * x + plan.h_eps * eps
+            x = plan.c_x * x + plan.c_eps * eps + (plan.c_hist * hist if plan.use_hist else 0.0)
+            hist = x0
+            prod.fused_commit()
+        else:
+            assert np.allclose(prod.scale_model_input(x, t).numpy(), want_in, atol=1e-5)
+            x = prod.step(eps, t, x)[0]
+        assert np.allclose(x.numpy(), xr, atol=2e-5), (name, mode, float(t))
+
+
+def test_unknown_timestep_is_rejected_by_sigma_schedulers():
+    s = schedulers.EulerDiscreteScheduler()
+    s.set_timesteps(10)
+    with pytest.raises(ValueError, match="not in the schedule"):
+        s.scale_model_input(torch.zeros(1), 123.0)
+
+
 def test_pipeline_host_logic_matches_oracle_loop(golden):
     """StableDiffusionUnifiedPipeline (product host code) driving oracle-backed doubles must equal
     the oracle's own loop: checks CFG order, scheduler wiring, un-scaling and decode call."""
