@@ -43,6 +43,29 @@ def denoise_ref(unet_cfg, unet_w, latents, prompt_embeds_2b, steps, guidance_sca
 
 
 @torch.no_grad()
+def img2img_denoise_ref(unet_cfg, unet_w, init_latents, noise, prompt_embeds_2b, steps, strength,
+                        guidance_scale=5.0, scheduler="DDIM", added_cond_kwargs=None):
+    """img2img branch `/root/reference/pipelines/sd_unified_pipeline.py:236-264`: get_timesteps (`:722-761`,
+    t_start = steps - min(int(steps * strength), steps)), add_noise of the initial latents at the first kept
+    timestep (`:841`), then the loop `:465-507` over timesteps[t_start:].  `noise` is handed in (the product
+    draws it from a seeded device generator; the test reproduces that draw)."""
+    sch = SCHEDULERS[scheduler]()
+    ts = sch.set_timesteps(steps)
+    t_start = max(steps - min(int(steps * strength), steps), 0)
+    ts = ts[t_start:]
+    if hasattr(sch, "start_at"):
+        sch.start_at(ts[0])
+    x = sch.add_noise(init_latents.double().numpy(), noise.double().numpy(), ts[0])
+    for t in ts:
+        xin = sch.scale_model_input(np.concatenate([x, x], axis=0), t)
+        eps = unet_forward(unet_cfg, unet_w, torch.from_numpy(xin).float(), torch.tensor(float(t)),
+                           prompt_embeds_2b, added_cond_kwargs).double().numpy()
+        e_u, e_t = np.split(eps, 2, axis=0)
+        x = sch.step(guidance_scale * (e_t - e_u) + e_u, t, x)
+    return torch.from_numpy(x).float()
+
+
+@torch.no_grad()
 def txt2img_ref(unet_cfg, unet_w, vae_cfg, vae_w, latents, prompt_embeds_2b, steps,
                 guidance_scale=5.0, scheduler="DDIM", added_cond_kwargs=None):
     lat = denoise_ref(unet_cfg, unet_w, latents, prompt_embeds_2b, steps, guidance_scale,

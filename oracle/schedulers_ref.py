@@ -87,6 +87,12 @@ class DPMpp2MRef:
     def scale_model_input(self, x, t):
         return x
 
+    def add_noise(self, x0, noise, t):
+        """diffusers DPMSolverMultistepScheduler.add_noise: alpha_t x0 + sigma_t noise at the schedule
+        position of `t`."""
+        a, sg = self._alpha_sigma(self.sigmas[int(np.nonzero(self.timesteps == int(t))[0][0])])
+        return a * x0 + sg * noise
+
     def start_at(self, t):
         """Loop entered mid-schedule (img2img strength < 1 / denoising_start): diffusers resolves the
         step index from the first timestep it is given (`_init_step_index`)."""

@@ -24,7 +24,19 @@ namespace {
 constexpr int BK = 64;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// Wait until at most `y` (wave-uniform, 0 <= y <= YMAX) ring stages of PER DMA instructions each are
+// still in flight: the immediate has to be a literal, so the count is dispatched over a short chain.
+template <int PER, int YMAX>
+__device__ __forceinline__ void wait_stages(int y) {
+    if constexpr (YMAX == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (y >= YMAX) wait_vmcnt<PER * YMAX>();
+        else wait_stages<PER, YMAX - 1>(y);
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool PW, bool STAG, int BKT>
@@ -36,7 +48,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     static_assert(BKT == 64 || BKT == 32, "K slab depth");
     static_assert((BM / (512 / BKT)) % (WAVES_M * WAVES_N) == 0, "A-tile DMA rows must divide over the waves");
     static_assert((BM / WAVES_M) % 16 == 0 && (BN / WAVES_N) % 16 == 0, "wave tile must be MFMA-shaped");
-    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 8, "ring depth");
 
     // The body is device-only: clang's host pass cannot type-check the gfx950 LDS-DMA builtin
     // (16-byte size) and would silently drop the kernel's host stub.
@@ -192,13 +204,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
             // stage kt must have landed; at most D-1 younger stages may stay in flight
             {
                 const int rem = nk - 1 - kt;
-                if (D >= 3 && rem >= 2) {
-                    if (b_hi) wait_vmcnt<2 * LPW>(); else wait_vmcnt<2 * LPW_LO>();
-                } else if (D >= 2 && rem >= 1) {
-                    if (b_hi) wait_vmcnt<LPW>(); else wait_vmcnt<LPW_LO>();
-                } else {
-                    wait_vmcnt<0>();
-                }
+                const int y = rem < D - 1 ? rem : D - 1;
+                if (b_hi) wait_stages<LPW, D - 1>(y); else wait_stages<LPW_LO, D - 1>(y);
             }
             __builtin_amdgcn_s_barrier();
             // (kt + D) % STAGES == (kt - 1) % STAGES.  With STAG the second wave group (the SIMD partners
@@ -736,6 +743,11 @@ int g_force_splits = 0;
 //   8 / 9: 128x64 / 128x160 with a 3-deep ring: only pays on the small-M, deep-K shapes of the 8x8 and
 //          16x16 levels when their weights come cold from HBM (as they do inside a forward); with the
 //          weights cache-resident the 2-deep rings win everywhere (tools/tune_igemm.py, SD_BENCH_COLD_MB)
+//   11 / 12: 128x64 with a 4- / 6-deep ring, 13: 64x64 6-deep, 14: 128x128 4-deep, 15: 128x160 4-deep.
+//          Grids of <= 2 blocks per CU (the 16x16 / 8x8-level linears: M = 512..2048) have no second block
+//          to hide a K step's L2 round trip behind: with prefetch distance 1 every 64-deep step costs
+//          that round trip (0.4-0.5 us against 0.12 us of MFMAs); a ring deep enough to keep 3-5 slabs
+//          in flight makes the loop MFMA-paced after the prologue.
 // printf formats of the kernel names as rocprofv3 prints them (%s = the pointwise flag)
 static const char* kIgemm2Names[] = {
     "igemm2_kernel<256,128,4,2,3,%s,false,64>", "igemm2_kernel<128,128,2,2,2,%s,false,64>",
@@ -743,8 +755,11 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
     "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
-    "conv3x3_halo_kernel"};
-constexpr int kNumVariants = 11;
+    "conv3x3_halo_kernel",
+    "igemm2_kernel<128,64,2,2,4,%s,false,64>",  "igemm2_kernel<128,64,2,2,6,%s,false,64>",
+    "igemm2_kernel<64,64,2,2,6,%s,false,64>",   "igemm2_kernel<128,128,2,2,4,%s,false,64>",
+    "igemm2_kernel<128,160,2,2,4,%s,false,64>"};
+constexpr int kNumVariants = 16;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -757,7 +772,8 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}, {256, 160}};
+                                               {128, 64}, {128, 160}, {256, 160},
+                                               {128, 64}, {128, 64}, {64, 64}, {128, 128}, {128, 160}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -775,16 +791,16 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
-        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6) *variant = 1;
+        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6 && *variant != 14) *variant = 1;
         if (p.geglu || p.act) *splits = 1;
-        if (*variant >= 10 && !halo_supported(p)) *variant = 7;
+        if (*variant == 10 && !halo_supported(p)) *variant = 7;
         return;
     }
     for (const TunedEntry& e : kTuned)
         if (!p.act && e.M == p.M && e.N == p.Cout && e.K == p.K && e.ks == p.KS && e.stride == p.stride && e.up == p.up &&
             e.geglu == p.geglu) {
             *variant = e.variant; *splits = e.splits;
-            if (*variant >= 10 && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
+            if (*variant == 10 && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
             return;
         }
     const int nk = p.K / BK;
@@ -841,6 +857,11 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 8: return launch_v2<128, 64, 2, 2, 3>(p, partial, sp, s);
         case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
         case 10: return launch_halo(p, partial, sp, s);
+        case 11: return launch_v2<128, 64, 2, 2, 4>(p, partial, sp, s);
+        case 12: return launch_v2<128, 64, 2, 2, 6>(p, partial, sp, s);
+        case 13: return launch_v2<64, 64, 2, 2, 6>(p, partial, sp, s);
+        case 14: return launch_v2<128, 128, 2, 2, 4>(p, partial, sp, s);
+        case 15: return launch_v2<128, 160, 2, 2, 4>(p, partial, sp, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

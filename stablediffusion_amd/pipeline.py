@@ -42,7 +42,11 @@ class SDModelWrapper:
             self.text_encoder_2 = text_encoder_2
             self.tokenizer_2 = tokenizer_2
         self.scheduler = scheduler if scheduler is not None else _sched.EulerDiscreteScheduler()
-        self.scheduler_name = "euler"
+        # the reference leaves `scheduler_name` unset until the first set_scheduler (hasattr check,
+        # models/stable_diffusion.py:200); it is only pre-set here when it is known to be true, so that
+        # set_scheduler("euler") on a wrapper built around another scheduler really switches
+        if isinstance(self.scheduler, _sched.EulerDiscreteScheduler):
+            self.scheduler_name = "euler"
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
         self.device = torch.device(device)
         self.type = model_type

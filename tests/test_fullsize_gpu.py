@@ -147,3 +147,130 @@ def test_c2_loop_and_decode_at_benchmark_size(engine_lib, steps):
     diff = abs(u8 - u8_ref)
     print(f"c2 loop, {steps} steps: uint8 mean |d|", diff.mean(), "within 4 levels", (diff <= 4).mean())
     assert diff.mean() <= 1.0 and (diff <= 4).mean() >= 0.995
+
+
+# ------------------------------------------------------------------------------------------------
+# Configs C4 and C5 at their own sizes
+# ------------------------------------------------------------------------------------------------
+
+class _oracle_on_gpu:
+    """Route the oracle loop's UNet / VAE calls to the fp32 GPU evaluation (same code, cuda tensors)."""
+
+    def __enter__(self):
+        from oracle import pipeline_ref
+        self.p = pipeline_ref
+        self.saved = (pipeline_ref.unet_forward, pipeline_ref.vae_decode, unet_ref.timestep_sinusoid)
+        ou, ov, os_ = self.saved
+
+        def _u(c, w, x, t, e, a=None):
+            a = {k: v.cuda() for k, v in a.items()} if a else None
+            return ou(c, w, x.cuda(), t, e.cuda(), a).cpu()
+        pipeline_ref.unet_forward = _u
+        pipeline_ref.vae_decode = lambda c, w, z: ov(c, w, z.cuda()).cpu()
+        unet_ref.timestep_sinusoid = lambda tt, *a, **k: os_(tt.cpu(), *a, **k).cuda()
+        return pipeline_ref
+
+    def __exit__(self, *exc):
+        self.p.unet_forward, self.p.vae_decode, unet_ref.timestep_sinusoid = self.saved
+
+
+@pytest.mark.parametrize("name,cfg_fn,B,hw", [("C4 SDXL VAE, 1024 px, batch 2", config.sdxl_vae, 2, 128),
+                                              ("C5 SD1.5 VAE, 768 px, batch 4", config.sd15_vae, 4, 96)])
+def test_vae_decode_and_encode_at_c4_c5_size(engine_lib, name, cfg_fn, B, hw):
+    """`sd_unified_pipeline.py:511-523` (decode) and `:1020-1036` (encode for img2img) at the image sizes of
+    BASELINE.json C4 (1024 px, batch 2) and C5 (768 px, batch 4)."""
+    cfg = cfg_fn()
+    sd = weights.synth_state_dict(weights.vae_manifest(cfg), seed=44, dtype=torch.float16, perturb=0.1)
+    vae = HipAutoencoderKL(cfg).load_state_dict(sd)
+    w32 = {k: v.float().cuda() for k, v in sd.items()}
+    z = (torch.randn(B, 4, hw, hw, generator=torch.Generator().manual_seed(hw)) * 1.5).half()
+    got = vae.decode(z.cuda())[0]
+    with torch.no_grad():
+        ref = vae_ref.vae_decode(cfg, w32, z.float().cuda())
+    assert got.shape == (B, 3, 8 * hw, 8 * hw) and torch.isfinite(got.float()).all()
+    print(name, "decode rel-L2", rel_l2(got, ref))
+    assert rel_l2(got, ref) < TOL, name
+    del ref
+    img = got.clamp(-1, 1)
+    enc = vae.encode_moments(img)
+    with torch.no_grad():
+        ref_m = vae_ref.vae_encode_moments(cfg, w32, img.float())
+    assert torch.isfinite(enc.float()).all()
+    print(name, "encode rel-L2", rel_l2(enc[:, :4], ref_m[:, :4]))
+    assert rel_l2(enc[:, :4], ref_m[:, :4]) < TOL, name
+
+
+def test_c4_sdxl_dpmpp2m_loop_at_benchmark_size(engine_lib):
+    """BASELINE.json C4: SDXL-base, 1024 px (128x128 latents), 30-step DPM++ 2M, batch 2, CFG on -- the engine
+    pipeline (device-fused CFG + scheduler update) against the oracle loop (numpy float64 DPM++ 2M, fp32 UNet
+    on the GPU), all 30 steps; the latents are compared (the 1024 px decode has its own test above)."""
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = config.sdxl_unet(), config.sdxl_vae()
+    usd = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=61, dtype=torch.float16)
+    vsd = weights.synth_state_dict(weights.vae_manifest(vcfg), seed=62, dtype=torch.float16)
+    model = SDModelWrapper(base=HipUNet2DConditionModel(ucfg).load_state_dict(usd),
+                           vae=HipAutoencoderKL(vcfg).load_state_dict(vsd), scheduler=DDIMScheduler(), device="cuda",
+                           model_type="sdxl")
+    model.set_scheduler("DPM++ 2M")
+    g = torch.Generator().manual_seed(14)
+    B, steps = 2, 30
+    lat0 = torch.randn(B, 4, 128, 128, generator=g).half()
+    neg, pos = torch.randn(B, 77, 2048, generator=g).half(), torch.randn(B, 77, 2048, generator=g).half()
+    npool, pool = torch.randn(B, 1280, generator=g).half(), torch.randn(B, 1280, generator=g).half()
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda", output_type="latents")
+    got = pipe(model, prompt_embeds=pos.cuda(), negative_prompt_embeds=neg.cuda(), pooled_prompt_embeds=pool.cuda(),
+               negative_pooled_prompt_embeds=npool.cuda(), latents=lat0.cuda(), num_inference_steps=steps,
+               guidance_scale=5.0, height=1024, width=1024)
+    added = {"text_embeds": torch.cat([npool, pool]).float(),
+             "time_ids": torch.tensor([[1024.0, 1024, 0, 0, 1024, 1024]] * (2 * B))}
+    uw = {k: v.float().cuda() for k, v in usd.items()}
+    with _oracle_on_gpu() as pref:
+        ref = pref.denoise_ref(ucfg, uw, lat0.float(), torch.cat([neg, pos]).float(), steps=steps, guidance_scale=5.0,
+                               scheduler="DPM++ 2M", added_cond_kwargs=added)
+    assert got.shape == (B, 4, 128, 128) and torch.isfinite(got.float()).all()
+    print("C4 loop, 30-step DPM++ 2M: latents rel-L2", rel_l2(got, ref))
+    assert rel_l2(got, ref) < TOL
+
+
+@pytest.mark.parametrize("sched", ["DDIM", "euler"])
+def test_c5_img2img_with_fused_lora_at_full_width(engine_lib, sched):
+    """BASELINE.json C5: full-width SD1.5 UNet with a rank-16 LoRA (alpha = rank; on to_q / to_k / to_v / to_out.0
+    as the reference trainer writes it, `train_lora_pipeline.py:247-252`) fused on load, img2img at 96x96
+    latents (768 px), batch 4, strength 0.6 of 10 steps -> 6 steps entered mid-schedule
+    (`sd_unified_pipeline.py:236-264`, `:722-761`).  The noise the product draws from its seeded device
+    generator is reproduced with the same generator and handed to the oracle."""
+    from stablediffusion_amd.pipeline import SDModelWrapper, StableDiffusionUnifiedPipeline
+    from stablediffusion_amd.schedulers import DDIMScheduler
+    ucfg, vcfg = config.sd15_unet(), config.sd15_vae()
+    base = weights.synth_state_dict(weights.unet_manifest(ucfg), seed=71, dtype=torch.float16)
+    g = torch.Generator().manual_seed(5)
+    lora = {}
+    for k, w in base.items():
+        if k.endswith(("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight")):
+            mod = k[: -len(".weight")]
+            lora[f"unet.{mod}.lora.down.weight"] = torch.randn(16, w.shape[1], generator=g) * (w.shape[1] ** -0.5)
+            lora[f"unet.{mod}.lora.up.weight"] = torch.randn(w.shape[0], 16, generator=g) * 0.05
+    fused = {k: v.half() for k, v in weights.fuse_lora({k: v.float() for k, v in base.items()}, lora,
+                                                       adapter_weight=0.8).items()}
+    k0 = "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight"
+    assert not torch.equal(fused[k0], base[k0])
+    vsd = weights.synth_state_dict(weights.vae_manifest(vcfg), seed=72, dtype=torch.float16)
+    model = SDModelWrapper(base=HipUNet2DConditionModel(ucfg).load_state_dict(fused),
+                           vae=HipAutoencoderKL(vcfg).load_state_dict(vsd), scheduler=DDIMScheduler(), device="cuda")
+    model.set_scheduler(sched)
+    B, steps, strength, seed = 4, 10, 0.6, 11
+    init = torch.randn(B, 4, 96, 96, generator=g).half()
+    neg, pos = torch.randn(B, 77, 768, generator=g).half(), torch.randn(B, 77, 768, generator=g).half()
+    pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device="cuda", output_type="latents")
+    got = pipe(model, prompt_embeds=pos.cuda(), negative_prompt_embeds=neg.cuda(), image=init.cuda(), strength=strength,
+               num_inference_steps=steps, guidance_scale=5.0, seed=seed)
+    noise = torch.randn(init.shape, generator=torch.Generator(device="cuda").manual_seed(seed), device="cuda",
+                        dtype=torch.float16).cpu()
+    uw = {k: v.float().cuda() for k, v in fused.items()}
+    with _oracle_on_gpu() as pref:
+        ref = pref.img2img_denoise_ref(ucfg, uw, init.float(), noise.float(), torch.cat([neg, pos]).float(), steps=steps,
+                                       strength=strength, guidance_scale=5.0, scheduler=sched)
+    assert got.shape == (B, 4, 96, 96) and torch.isfinite(got.float()).all()
+    print(f"C5 img2img + LoRA, {sched}: latents rel-L2", rel_l2(got, ref))
+    assert rel_l2(got, ref) < TOL

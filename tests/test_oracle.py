@@ -230,6 +230,12 @@ def test_pipeline_img2img_and_errors(golden):
     with pytest.raises(ValueError):
         model.set_scheduler("nope")
     model.set_scheduler("DPM++ 2M")
+    assert type(model.scheduler).__name__ == "DPMSolverMultistepScheduler"
+    # a wrapper built around a non-default scheduler must really switch to "euler" (r2: it used to
+    # believe it already was "euler" and kept the DDIM object)
+    m2 = SDModelWrapper(base=model.base, vae=model.vae, scheduler=schedulers.DDIMScheduler(), device="cpu")
+    m2.set_scheduler("euler")
+    assert type(m2.scheduler).__name__ == "EulerDiscreteScheduler"
     assert isinstance(model.scheduler, schedulers.DPMSolverMultistepScheduler)
 
 
