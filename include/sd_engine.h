@@ -226,6 +226,15 @@ int sd_igemm_force(int variant, int splits);
 int sd_op_conv2d(const void* x_nhwc, const void* w_oihw, const void* bias, const void* rowadd,
                  const void* res_nhwc, void* y_nhwc, int N, int H, int W, int Cin, int Cout,
                  int ksize, int stride, int upsample2x, int geglu, void* stream);
+/* Convolution followed by GroupNorm (+ SiLU) of its output, the pair ResnetBlock2D issues as
+ * conv1 -> norm2 and the VAE decoder as conv2 -> next norm1 (diffusers resnet.py under
+ * sd_unified_pipeline.py:475-482, :523).  When the launch allows it the convolution's epilogue leaves
+ * the GroupNorm statistics and the GroupNorm makes no pass of its own over y_conv;
+ * *stats_from_epilogue (may be NULL) tells which path ran.  y_conv and y_gn are both written. */
+int sd_op_conv2d_groupnorm(const void* x_nhwc, const void* w_oihw, const void* bias, const void* rowadd,
+                           const void* res_nhwc, void* y_conv_nhwc, const void* gamma, const void* beta,
+                           void* y_gn_nhwc, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
+                           int upsample2x, int groups, float eps, int silu, int* stats_from_epilogue, void* stream);
 /* Same operator, timed: `iters` back-to-back launches bracketed by HIP events on `stream`
  * (after two warm-up launches); used by tools/tune_igemm.py to pick tile variants per shape. */
 int sd_bench_conv2d(const void* x_nhwc, const void* w_oihw, void* y_nhwc, int N, int H, int W, int Cin,

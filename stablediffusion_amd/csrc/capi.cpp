@@ -241,9 +241,15 @@ int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries) {
 
 // ------------------------------------------------------------------------- single-operator entries
 // Test / tuner path only: packs the weight on every call (allocation + sync); never used by the models.
+// Optional GroupNorm behind the convolution (sd_op_conv2d_groupnorm): the conv's epilogue leaves the
+// GroupNorm summaries when the launch can (igemm2_emits_gnstats), the GroupNorm then skips its own pass.
+struct GnTail {
+    const float* gamma; const float* beta; void* y; int groups; float eps; int silu; int* fused;
+};
+
 static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
                        void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int upsample2x,
-                       int geglu, void* stream, int iters, float* ms_out) {
+                       int geglu, void* stream, int iters, float* ms_out, const GnTail* gn = nullptr) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long K = (long)ksize * ksize * Cin;
     if (K % 64 != 0 || Cin % 64 != 0) { set_error("sd_op_conv2d: Cin must be a multiple of 64"); return SD_ERR_INVALID; }
@@ -295,6 +301,20 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
             const long pf = igemm2_partial_floats(p);
             if (pf > 0) SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&partial), (size_t)pf * sizeof(float)));
         }
+        float* gnbuf = nullptr;
+        float* gnscratch = nullptr;
+        GnStats gst;
+        if (gn) {
+            int rows = 0;
+            if (gn->fused) *gn->fused = 0;
+            SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gnscratch), (size_t)gn_scratch_floats(N, (long)p.OH * p.OW, Cout, gn->groups) * 4));
+            if (igemm2_emits_gnstats(p, gn->groups, &rows)) {
+                SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gnbuf), (size_t)gnstat_floats(N, (long)p.OH * p.OW, gn->groups) * 4));
+                p.gnstat_out = gnbuf; p.gn_groups = gn->groups;
+                gst.part = gnbuf; gst.rows = rows; gst.S = p.OH * p.OW / rows;
+                if (gn->fused) *gn->fused = 1;
+            }
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ms_out) { SD_HIP_CHECK(hipEventCreate(&e0)); SD_HIP_CHECK(hipEventCreate(&e1)); }
         // SD_BENCH_COLD_MB=<n> (tuner): rotate through copies of the packed weights totalling n MB, so
@@ -328,6 +348,10 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
             if (wring) p.w = reinterpret_cast<half_t*>(reinterpret_cast<char*>(wring) + wbytes * (size_t)(it % nrot));
             rc = v2 ? launch_igemm2(p, partial, s) : launch_igemm(p, s);
         }
+        if (gn && !rc)
+            rc = launch_groupnorm(p.y, p.ldy, gn->gamma, gn->beta, static_cast<half_t*>(gn->y), Cout, N, (long)p.OH * p.OW, Cout,
+                                  gn->groups, gn->eps, gn->silu, gnscratch, s, gst.part ? &gst : nullptr);
+        if (gn) { (void)hipStreamSynchronize(s); if (gnbuf) (void)hipFree(gnbuf); (void)hipFree(gnscratch); }
         if (ms_out && !rc) {
             SD_HIP_CHECK(hipEventRecord(e1, s));
             SD_HIP_CHECK(hipEventSynchronize(e1));
@@ -351,6 +375,16 @@ int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const 
                  int geglu, void* stream) {
     return conv2d_impl(x, w_oihw, bias_f32, rowadd_f32, res, y, N, H, W, Cin, Cout, ksize, stride, upsample2x, geglu,
                        stream, 1, nullptr);
+}
+
+int sd_op_conv2d_groupnorm(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
+                           void* y_conv, const void* gamma_f32, const void* beta_f32, void* y_gn, int N, int H, int W,
+                           int Cin, int Cout, int ksize, int stride, int upsample2x, int groups, float eps, int silu,
+                           int* stats_from_epilogue, void* stream) {
+    GnTail gn{static_cast<const float*>(gamma_f32), static_cast<const float*>(beta_f32), y_gn, groups, eps, silu,
+              stats_from_epilogue};
+    return conv2d_impl(x, w_oihw, bias_f32, rowadd_f32, res, y_conv, N, H, W, Cin, Cout, ksize, stride, upsample2x, 0,
+                       stream, 1, nullptr, &gn);
 }
 
 int sd_bench_conv2d(const void* x, const void* w_oihw, void* y, int N, int H, int W, int Cin, int Cout, int ksize,

@@ -48,6 +48,29 @@ struct ConvW {          // conv or linear, packed [rows_pad][K] fp16 + fp32 bias
     float* bias = nullptr;
     int cin = 0, cout = 0, ks = 1;
     long K = 0;         // packed K (>= ks*ks*cin, multiple of 64)
+    float* wsum = nullptr;   // row sums of the packed weights: set when a LayerNorm was folded in (fold_ln)
+};
+// Per-row (sum, sum of squares) partials of an activation tensor, `parts` pairs per row: written by
+// the GEMM that produced the tensor (or by launch_row_stats), consumed by the GEMM that applies the
+// folded LayerNorm (IGemmParams::rowstat_out / ln_stat).
+struct RowStat {
+    float* p = nullptr;
+    int parts = 0;
+};
+// GroupNorm summaries of an activation tensor written by the convolution that produced it: `buf` is
+// caller-allocated (gnstat_floats), `st` is filled in by op_conv when the launch really emits them
+// (st.part == nullptr otherwise: the GroupNorm then runs its own statistics pass).
+struct GnStatBuf {
+    float* buf = nullptr;
+    GnStats st;
+};
+// What an op_conv launch fuses besides bias / row add / residual / GEGLU / activation.
+struct ConvFuse {
+    const RowStat* ln_in = nullptr;     // LayerNorm of the INPUT, folded into this linear (ConvW::wsum set)
+    float ln_eps = 0.f;
+    RowStat* stat_out = nullptr;        // row statistics of the OUTPUT for the LayerNorm that follows
+    GnStatBuf* gn_out = nullptr;        // GroupNorm summaries of the OUTPUT for the GroupNorm that follows
+    int gn_groups = 0;
 };
 struct NormW {
     float* gamma = nullptr;
@@ -75,6 +98,9 @@ class WeightStore {
                   ConvW* out);                                  // row-concatenated linears
     int pack_geglu(const std::string& prefix, ConvW* out);      // [8C][C] -> 64-row interleave
     int pack_norm(const std::string& prefix, NormW* out);
+    // Fold LayerNorm `ln` (applied to the GEMM's input) into the packed linear `w`: W <- W diag(gamma)
+    // (rows < rows_scaled additionally times row_scale), bias <- bias + W beta, w->wsum = row sums.
+    int fold_ln(ConvW* w, const NormW& ln, int rows_scaled, float row_scale);
     void free_raw();
     void* dmalloc(size_t bytes);                                // tracked device allocation
     int64_t packed_bytes() const { return packed_bytes_; }
@@ -94,7 +120,16 @@ struct Ctx {
     hipStream_t stream;
     bool dry;
     int err = 0;
+    // Ring of GroupNorm-summary buffers (ctx_gnpool_init at the top of a forward): a convolution whose
+    // output goes into a GroupNorm takes the next slot (ctx_gnbuf) and the GroupNorm reads it one or two
+    // launches later, long before the ring comes round again.
+    static constexpr int kGnPool = 4;
+    GnStatBuf gnpool[kGnPool];
+    int gn_next = 0;
+    int gn_groups = 0;
 };
+void ctx_gnpool_init(Ctx& c, int N, long HW_max, int G);
+GnStatBuf* ctx_gnbuf(Ctx& c);       // next ring slot with `st` cleared; nullptr when the pool is not set up
 
 // ---- optional per-launch timing (bench.py's live roofline): HIP events on the launch stream ----
 struct ProfAgg { double flops = 0, bytes = 0, ms = 0; long launches = 0; };
@@ -107,8 +142,13 @@ int prof_collect(std::map<std::string, ProfAgg>* out);   // synchronises, aggreg
 // ---- op wrappers: skip the launch in dry mode, latch the first error ----
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride = 1, int up = 0,
              const float* rowadd = nullptr, int rowadd_ld = 0, const View* res = nullptr, int geglu = 0,
-             int pad = -1, int act = 0);
-void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu);
+             int pad = -1, int act = 0, const ConvFuse* fuse = nullptr);
+// floats a RowStat buffer needs for an [M, C] tensor whatever tile the producer picks
+inline long rowstat_floats(long M, int C) { return M * ((C + 63) / 64) * 2; }
+// floats a GnStatBuf needs for N images of HW pixels (tiles of >= 64 pixels) and G groups
+inline long gnstat_floats(int N, long HW, int G) { return (long)N * ((HW + 63) / 64) * G * 2; }
+void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu,
+                  const GnStatBuf* pre = nullptr);
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps);
 void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal = 0,
                   int prescaled = 0);

@@ -22,6 +22,7 @@ namespace sd {
 namespace {
 
 constexpr int BK = 64;
+constexpr int kMaxLnParts = 20;     // row-statistics partials a LayerNorm consumer reads per row, at most
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
@@ -36,6 +37,49 @@ __device__ __forceinline__ void wait_stages(int y) {
     } else {
         if (y >= YMAX) wait_vmcnt<PER * YMAX>();
         else wait_stages<PER, YMAX - 1>(y);
+    }
+}
+
+// LDS layout shared by the kernel and its launcher: [ring | epilogue staging + row-statistics partials]
+// overlaid, then the LayerNorm row statistics of a consumer launch (written in the prologue, read in
+// the epilogue, so outside everything the main loop touches).
+template <int BM, int BN, int STAGES, int BKT>
+struct IGemm2Lds {
+    static constexpr int RING = STAGES * (BM + BN) * BKT * 2;
+    static constexpr int EPI = BM * (BN + 8) * 2;
+    static constexpr int RED = BM * (BN / 8) * 8;        // row-statistics chunk partials
+    static constexpr int GRED = 512 * 16;                // GroupNorm partials, 4 floats per thread
+    static constexpr int MAIN = RING > EPI + RED + GRED ? RING : EPI + RED + GRED;
+    static constexpr int TOTAL = MAIN + BM * 8;
+};
+
+// GroupNorm summaries of one output tile (all BM rows inside one image): every thread hands in the
+// sums / sums of squares of its column chunk's channels, split over the (at most two) groups the chunk
+// touches; one thread per group of the tile adds them in a fixed order and stores
+// (mean, M2 = Q - S * mean) at dst[g * 2].  Tile-level plain sums (BM * cpg <= a few thousand values),
+// merged across tiles with chan_merge by the consumer.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void gn_tile_stats(float* sG, int tid, float gs0, float gq0, float gs1, float gq1, int n0,
+                                              int Cout, int cpg, int groups, float* dst) {
+    constexpr int CH = BN / 8;
+    constexpr int RPP = NT / CH;
+    *reinterpret_cast<f4*>(sG + tid * 4) = f4{gs0, gq0, gs1, gq1};
+    __syncthreads();
+    const int cols = Cout - n0 < BN ? Cout - n0 : BN;
+    const int ng = cols / cpg;                           // groups of this tile (tile columns start on a group)
+    if (tid < ng) {
+        const int g = n0 / cpg + tid;                    // global group
+        const int cfirst = (tid * cpg) / 8, clast = ((tid + 1) * cpg - 1) / 8;
+        float sm = 0.f, sq = 0.f;
+        for (int c8 = cfirst; c8 <= clast; ++c8) {
+            const int part = ((n0 + c8 * 8) / cpg == g) ? 0 : 2;     // the chunk's first group, or its second
+            for (int rr = 0; rr < RPP; ++rr) {
+                const float2 v = *reinterpret_cast<const float2*>(sG + (rr * CH + c8) * 4 + part);
+                sm += v.x; sq += v.y;
+            }
+        }
+        const float mean = sm / (float)(BM * cpg);
+        *reinterpret_cast<float2*>(dst + (long)g * 2) = float2{mean, sq - sm * mean};
     }
 }
 
@@ -70,9 +114,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     constexpr int LPW_LO = A_PW + B_PW - 1;     // waves >= B_REM when uneven
     constexpr int STAGE_HALVES = (BM + BN) * BKT;
     constexpr int LDC = BN + 8;
+    using L = IGemm2Lds<BM, BN, STAGES, BKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* ring = reinterpret_cast<half_t*>(smem);
     half_t* sC = reinterpret_cast<half_t*>(smem);
+    float* sRed = reinterpret_cast<float*>(smem + L::EPI);      // [BM][BN / 8][2] row-statistics partials (producer)
+    float* sG = reinterpret_cast<float*>(smem + L::EPI + L::RED);   // [NT][4] GroupNorm partials (producer)
+    float* sStat = reinterpret_cast<float*>(smem + L::MAIN);    // [BM][2] mean, rstd of the block's rows (LN consumer)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -193,6 +241,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     for (int s = 0; s < D; ++s)
         if (s < nk) issue(s);
 
+    // LayerNorm consumer: mean / rstd of the block's rows from the producer's partial sums, computed
+    // while the first slabs are in flight (the compiler's vmcnt(0) ahead of these plain loads' first
+    // use also covers the prologue DMAs, which the first step waits for anyway) and parked in LDS
+    // beyond everything the main loop touches; the epilogue's first barrier publishes them.
+    if (p.ln_stat) {
+        static_assert(NT >= BM, "one thread per tile row");
+        if (tid < BM) {
+            const int m = m0 + tid;
+            // all of the row's partials (at most kMaxLnParts: C <= 1280 behind 64-column producer tiles) are
+            // loaded in one batch -- a loop with a runtime trip count issued them one L2 round trip at a time
+            float2 pv[kMaxLnParts];
+            const float2* src = reinterpret_cast<const float2*>(p.ln_stat) + (long)(m < p.M ? m : 0) * p.ln_parts;
+            // (every load unconditional, at a clamped index: a select around a load makes hipcc branch and
+            // wait per element)
+#pragma unroll
+            for (int k = 0; k < kMaxLnParts; ++k) pv[k] = src[k < p.ln_parts ? k : p.ln_parts - 1];
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxLnParts; ++k) {
+                sm += k < p.ln_parts ? pv[k].x : 0.f;
+                sq += k < p.ln_parts ? pv[k].y : 0.f;
+            }
+            const float inv = 1.0f / (float)p.ln_C;
+            const float mean = sm * inv;
+            float var = sq * inv - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            sStat[tid * 2] = mean;
+            sStat[tid * 2 + 1] = rsqrtf(var + p.ln_eps);
+        }
+    }
+
     const int fr = lane & 15, fq = lane >> 4;
     // The K loop is unrolled by the ring depth, so a step's ring slot (and the slot its DMA refills) is
     // compile-time; a step's scalar work is the wait, the barrier and the issue's address updates.
@@ -258,14 +337,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     //      in a batch ahead of its first use: one load-and-wait per accumulator tile (bias, row add) and
     //      per output chunk (residual) serialises 20-30 L2 round trips per block otherwise. ----
     __syncthreads();     // every wave is done with the ring before it is overlaid
-    f4 bias4[TN];
+    f4 bias4[TN], wsum4[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
         bias4[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) : f4{0.f, 0.f, 0.f, 0.f};
+    if (p.ln_stat) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wsum4[j] = *reinterpret_cast<const f4*>(p.ln_wsum + n0 + wn * WTN + j * 16 + fq * 4);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pr = wm * WTM + i * 16 + fr;
         const int m = m0 + pr;
+        if (p.ln_stat) {     // y = rstd * (x W'^T - mean * wsum) + b'
+            const float mean = sStat[pr * 2], rstd = sStat[pr * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] - mean * wsum4[j]) * rstd;
+        }
         f4 add[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) add[j] = bias4[j];
@@ -313,34 +401,70 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
         }
         return;
     }
+    // Output pass: thread t owns the 16-byte column chunk t % CH of the rows t / CH + k * RPP (the last
+    // NT % CH threads sit out): a fixed column per thread, so the per-group sums a following GroupNorm
+    // needs accumulate in registers across the thread's rows.
     constexpr int CH = BN / 8;
-    constexpr int ITER = BM * CH / NT;
-    static_assert(BM * CH % NT == 0, "output chunks must divide over the threads");
+    constexpr int RPP = NT / CH;                 // tile rows per pass
+    constexpr int ITER = (BM + RPP - 1) / RPP;
+    const int c8 = tid % CH, rr = tid / CH;
+    const int c = c8 * 8, n = n0 + c;
+    const bool okc = rr < RPP && n < p.Cout;
     h8 rv[ITER];
     if (p.res) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int idx = tid + it * NT;
-            const int r = idx / CH, c = (idx - r * CH) * 8;
-            const int m = m0 + r, n = n0 + c;
-            rv[it] = (m < p.M && n < p.Cout) ? *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n)
-                                             : h8{0, 0, 0, 0, 0, 0, 0, 0};
+            const int r = rr + it * RPP;
+            const int m = m0 + r;
+            rv[it] = (okc && r < BM && m < p.M) ? *reinterpret_cast<const h8*>(p.res + (long)m * p.ldres + n)
+                                                : h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    // GroupNorm partials: the 8 channels of the chunk fall into at most two groups (cpg >= 8 or cpg == 4)
+    const int cpg = p.gnstat_out ? p.Cout / p.gn_groups : 8;
+    const int g_first = n / cpg;
+    const int gsplit = (g_first + 1) * cpg - n;          // channels e < gsplit belong to g_first
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int idx = tid + it * NT;
-        const int r = idx / CH, c = (idx - r * CH) * 8;
-        const int m = m0 + r, n = n0 + c;
-        if (m < p.M && n < p.Cout) {
+        const int r = rr + it * RPP;
+        const int m = m0 + r;
+        if (okc && r < BM && m < p.M) {
             h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
             if (p.res) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[it][e]);
             }
             *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + n) = v;
+            if (p.rowstat_out) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sm += f; sq += f * f; }
+                *reinterpret_cast<float2*>(sRed + (r * CH + c8) * 2) = float2{sm, sq};
+            }
+            if (p.gnstat_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    if (e < gsplit) { gs0 += f; gq0 += f * f; } else { gs1 += f; gq1 += f * f; }
+                }
+            }
         }
     }
+    // Row statistics of the stored tile for a LayerNorm that follows (IGemmParams::rowstat_out): the
+    // chunk partials are added per row in chunk order (fixed order: bitwise reproducible).
+    if (p.rowstat_out) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            const int nch = (p.Cout - n0 < BN ? p.Cout - n0 : BN) / 8;
+            float sm = 0.f, sq = 0.f;
+            for (int k = 0; k < nch; ++k) { const float2 v = *reinterpret_cast<const float2*>(sRed + (tid * CH + k) * 2); sm += v.x; sq += v.y; }
+            *reinterpret_cast<float2*>(p.rowstat_out + ((long)(m0 + tid) * p.rowstat_parts + tn) * 2) = float2{sm, sq};
+        }
+    }
+    if (p.gnstat_out)
+        gn_tile_stats<BM, BN, NT>(sG, tid, gs0, gq0, gs1, gq1, n0, p.Cout, cpg, p.gn_groups,
+                                  p.gnstat_out + ((long)(m0 / OHW) * (OHW / BM) + (m0 % OHW) / BM) * p.gn_groups * 2);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -630,32 +754,48 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         }
     }
     __syncthreads();
+    // output pass with a fixed column chunk per thread (see igemm2_kernel): 25 rows x 20 chunks per pass
     constexpr int CH = BN / 8;
-    constexpr int ITER = BM * CH / NT;
+    constexpr int RPP = NT / CH;
+    constexpr int ITER = (BM + RPP - 1) / RPP;
+    const int c8 = tid % CH, rr = tid / CH;
+    const int c = c8 * 8, n = n0 + c;
+    const bool okc = rr < RPP && n < p.Cout;
     h8 rv[ITER];
     if (p.res) {
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-            const int idx = tid + it * NT;
-            const int r = idx / CH, c = (idx - r * CH) * 8;
-            rv[it] = n0 + c < p.Cout ? *reinterpret_cast<const h8*>(p.res + (long)row_of(r) * p.ldres + n0 + c)
+            const int r = rr + it * RPP;
+            rv[it] = (okc && r < BM) ? *reinterpret_cast<const h8*>(p.res + (long)row_of(r) * p.ldres + n)
                                      : h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    const int cpg = p.gnstat_out ? p.Cout / p.gn_groups : 8;
+    const int g_first = n / cpg;
+    const int gsplit = (g_first + 1) * cpg - n;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int idx = tid + it * NT;
-        const int r = idx / CH, c = (idx - r * CH) * 8;
-        const int m = row_of(r), n = n0 + c;
-        if (n < p.Cout) {
+        const int r = rr + it * RPP;
+        if (okc && r < BM) {
             h8 v = *reinterpret_cast<const h8*>(sC + r * LDC + c);
             if (p.res) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[it][e]);
             }
-            *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + n) = v;
+            *reinterpret_cast<h8*>(p.y + (long)row_of(r) * p.ldy + n) = v;
+            if (p.gnstat_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    if (e < gsplit) { gs0 += f; gq0 += f * f; } else { gs1 += f; gq1 += f * f; }
+                }
+            }
         }
     }
+    if (p.gnstat_out)
+        gn_tile_stats<BM, BN, NT>(reinterpret_cast<float*>(smem + BM * LDC * 2), tid, gs0, gq0, gs1, gq1, n0, p.Cout, cpg,
+                                  p.gn_groups, p.gnstat_out + ((long)img * patches + pidx) * p.gn_groups * 2);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -694,9 +834,7 @@ int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s)
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG, int BKT>
 int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
-    constexpr size_t ring = (size_t)STAGES * (BM + BN) * BKT * sizeof(half_t);
-    constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(half_t);
-    constexpr size_t lds = ring > epi ? ring : epi;
+    constexpr size_t lds = IGemm2Lds<BM, BN, STAGES, BKT>::TOTAL;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
@@ -710,6 +848,8 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     const int eff_splits = cdiv(nk, per);
     IGemmParams q = p;
     q.mfast = weights_outweigh_activations(p);
+    q.rowstat_parts = cdiv(p.Cout, BN);
+    if (eff_splits > 1 && (p.rowstat_out || p.ln_stat)) { set_error("igemm2: row statistics / LayerNorm fold need splits == 1"); return 1; }
     hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
                        q, eff_splits > 1 ? partial : nullptr, per);
     SD_HIP_CHECK(hipGetLastError());
@@ -787,7 +927,42 @@ static const TunedEntry kTuned[] = {
 // distilled from the same measurements: 128x160 tiles whenever Cout is a multiple of 160 (every
 // UNet / VAE width is), 128x128 otherwise; narrow tiles for small, shallow problems; split-K until
 // about two blocks per CU (512) are in flight, keeping >= 12 K-slabs per slice.
+static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits);
+
 void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
+    igemm2_pick_raw(p, variant, splits);
+    if (p.ln_stat) *splits = 1;          // the LayerNorm correction lives in the fused epilogue only
+}
+
+bool igemm2_emits_rowstats(const IGemmParams& p, int* parts) {
+    if (!igemm2_supported(p) || p.geglu) return false;
+    int v, sp;
+    igemm2_pick(p, &v, &sp);
+    if (sp > 1 || v == 10) return false;
+    int bm, bn;
+    tile_dims(v, &bm, &bn);
+    *parts = cdiv(p.Cout, bn);
+    return *parts <= kMaxLnParts;
+}
+
+bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
+    if (!igemm2_supported(p) || p.geglu || groups <= 0 || p.Cout % groups != 0) return false;
+    const int cpg = p.Cout / groups;
+    if (!(cpg >= 8 || cpg == 4)) return false;          // a 16-byte chunk may touch at most two groups
+    int v, sp;
+    igemm2_pick(p, &v, &sp);
+    if (sp > 1) return false;
+    if (v == 10 && !halo_supported(p)) v = 7;
+    int bm, bn;
+    tile_dims(v, &bm, &bn);
+    const int OHW = p.OH * p.OW;
+    if (OHW % bm != 0) return false;                    // every tile inside one image
+    if (bn % cpg != 0 && p.Cout > bn) return false;     // group boundaries on tile boundaries
+    *rows = bm;
+    return true;
+}
+
+static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;

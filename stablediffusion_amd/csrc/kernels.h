@@ -31,7 +31,31 @@ struct IGemmParams {
     int mfast = 0;
     int act = 0;            // activation after bias, before residual (LDS-DMA kernels, no split-K):
                             // 0 none, 1 quick_gelu x*sigmoid(1.702x) (CLIP-L MLP), 2 exact-erf gelu (OpenCLIP MLP)
+    // ---- LayerNorm folded across the GEMM (LDS-DMA kernels, pointwise, no split-K) ----
+    // Producer side: the epilogue also writes, per output row and per column tile of this launch, the sum
+    // and the sum of squares of the fp16 values it stores: rowstat_out[(m * rowstat_parts + tile_n) * 2 + {0,1}].
+    float* rowstat_out = nullptr;
+    int rowstat_parts = 0;          // = column tiles of the launch (filled in by the launcher)
+    // Consumer side: y = LN(x) W^T + b with LN's affine folded into the weights at pack time
+    // (W' = W diag(gamma), b' = b + W beta, wsum_n = sum_k W'_nk) becomes
+    //     y[m, n] = rstd_m * (acc[m, n] - mean_m * wsum[n]) + b'[n],   acc = x W'^T on the raw x
+    // with mean / rstd of row m from the producer's partial sums (ln_parts of them, over ln_C channels).
+    const float* ln_stat = nullptr;
+    int ln_parts = 0, ln_C = 0;
+    float ln_eps = 0.f;
+    const float* ln_wsum = nullptr;
+    // ---- GroupNorm statistics of the output, for the GroupNorm that follows (LDS-DMA kernels, no split-K,
+    //      every tile inside one image, group boundaries on tile boundaries: igemm2_emits_gnstats) ----
+    // gnstat_out[((img * tiles_per_image + tile) * gn_groups + g) * 2 + {0,1}] = (mean, M2) of the tile's rows
+    // x the group's channels (the GnStats layout of launch_groupnorm)
+    float* gnstat_out = nullptr;
+    int gn_groups = 0;
 };
+// Whether launch_igemm2 will honour p.gnstat_out for `groups` groups; *rows = pixels per tile (GnStats::rows).
+bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows);
+// Whether launch_igemm2 will honour p.rowstat_out for this problem (LDS-DMA kernel, no split-K); when not,
+// the caller runs launch_row_stats on the output instead.  Fills *parts with the column-tile count.
+bool igemm2_emits_rowstats(const IGemmParams& p, int* parts);
 int launch_igemm(const IGemmParams& p, hipStream_t s);
 const char* igemm_variant(const IGemmParams& p);   // name of the tile variant launch_igemm picks
 // LDS-DMA pipeline variants (igemm2.hip); falls back to launch_igemm when !igemm2_supported().
@@ -49,11 +73,29 @@ constexpr int kWeightRowPad = 256;
 // ---------------------------------------------------------------------------------------------
 // GroupNorm over NHWC: x [N, HW, C] (ld), groups G.  `scratch` must hold gn_scratch_floats().
 long gn_scratch_floats(int N, long HW, int C, int G);
+// Statistics some earlier kernel already computed for x: per (sample, slab of `rows` consecutive pixels,
+// group) the pair (mean, M2 = sum (x - mean)^2), part[((n * S + slab) * G + g) * 2 + {0,1}].  Written by
+// a convolution's epilogue (IGemmParams::gnstat_out); launch_groupnorm then skips its own pass over x.
+struct GnStats {
+    const float* part = nullptr;
+    int S = 0;
+    long rows = 0;
+};
+// false for the small maps the single-kernel GroupNorm handles (it reads x once anyway)
+bool gn_wants_stats(long HW, int C, int G);
 int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float* beta,
                      half_t* y, long ldy, int N, long HW, int C, int G, float eps, int silu,
-                     float* scratch, hipStream_t s);
+                     float* scratch, hipStream_t s, const GnStats* pre = nullptr);
 int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta,
                      half_t* y, long ldy, long rows, int C, float eps, hipStream_t s);
+// stat[m * 2 + {0,1}] = sum, sum of squares of row m (the one-part form of IGemmParams::rowstat_out)
+int launch_row_stats(const half_t* x, long ldx, float* stat, long rows, int C, hipStream_t s);
+// Pack-time LayerNorm fold of a [rows][K] fp16 weight matrix, in place (rows < rows_scaled are also
+// multiplied by row_scale: the attention query pre-scale):  w[n][k] <- fp16(w[n][k] * gamma[k] * s_n),
+// wsum[n] = sum_k of the ROUNDED new row, bias[n] <- s_n * (bias_in[n] + sum_k w_old[n][k] * beta[k]).
+// bias_in may be null (no bias); bias / wsum are fp32 arrays of `rows` entries.
+int launch_ln_fold(half_t* w, long K, int rows, const float* gamma, const float* beta, const float* bias_in,
+                   float* bias, float* wsum, int rows_scaled, float row_scale, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Attention (attention.hip): out = softmax(q k^T / sqrt(d)) v per (batch, head)

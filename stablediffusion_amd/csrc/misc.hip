@@ -292,6 +292,32 @@ __global__ void scale_f16_kernel(half_t* __restrict__ x, long n, float scale) {
     if (i < n) x[i] = (half_t)((float)x[i] * scale);
 }
 
+// Pack-time LayerNorm fold (launch_ln_fold): one wave per weight row.
+__global__ __launch_bounds__(256) void ln_fold_kernel(half_t* __restrict__ w, long K, int rows,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias_in, float* __restrict__ bias,
+                                                      float* __restrict__ wsum, int rows_scaled, float row_scale) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    const float sc = n < rows_scaled ? row_scale : 1.0f;
+    half_t* row = w + (long)n * K;
+    float ws = 0.f, wb = 0.f;
+    for (long k = lane; k < K; k += 64) {
+        const float old = (float)row[k];
+        const half_t nw = (half_t)(old * gamma[k] * sc);
+        row[k] = nw;
+        ws += (float)nw;
+        wb += old * beta[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ws += __shfl_xor(ws, off); wb += __shfl_xor(wb, off); }
+    if (lane == 0) {
+        wsum[n] = ws;
+        bias[n] = sc * ((bias_in ? bias_in[n] : 0.f) + wb);
+    }
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -391,6 +417,14 @@ int launch_inpaint_blend(half_t* lat, const half_t* img, const half_t* noise, co
     const long n = (long)B * C * HW;
     if (n == 0) return 0;
     hipLaunchKernelGGL(inpaint_blend_kernel, grid1d(n), dim3(256), 0, s, lat, img, noise, mask, a, b, C, HW, n);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_ln_fold(half_t* w, long K, int rows, const float* gamma, const float* beta, const float* bias_in,
+                   float* bias, float* wsum, int rows_scaled, float row_scale, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, w, K, rows, gamma, beta, bias_in, bias, wsum,
+                       rows_scaled, row_scale);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -18,6 +18,7 @@ struct TBlock {
     NormW ln1, ln2, ln3;
     ConvW qkv, out1, q2, out2, ff1, ff2;
     int kv_off = 0;     // column offset of this block's [K | V] text projection in UNet::kv_all
+    bool fold = false;  // ln1 / ln2 / ln3 are folded into qkv / q2 / ff1 (no LayerNorm launches)
 };
 struct Xformer {
     NormW gn;
@@ -31,9 +32,12 @@ struct VaeAttn {
     int C = 0;
 };
 
+// x_stats: GroupNorm summaries of x left by the convolution that produced it (or nullptr);
+// *out_stats: where the block leaves the summaries of `out` for the GroupNorm that consumes it next.
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
-                const float* tproj, int tproj_ld);
-void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L);
+                const float* tproj, int tproj_ld, const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr);
+void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L,
+                 const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr);
 
 struct UNet {
     explicit UNet(const sd_unet_config& c);
@@ -116,7 +120,8 @@ struct VAE {
     int pack_resnet(const std::string& p, Resnet* r);
     int pack_attn(const std::string& p, VaeAttn* a);
     int pack_pointwise(const std::string& p, half_t** w, float** b);
-    void run_attn(Ctx& c, const VaeAttn& a, View x, int N, int H, int W, View out);
+    void run_attn(Ctx& c, const VaeAttn& a, View x, int N, int H, int W, View out, const GnStatBuf* x_stats,
+                  GnStatBuf** out_stats);
     int run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w);
     int run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W);
 };

@@ -23,11 +23,28 @@ __host__ __device__ inline int gn_block_channels(int C, int G) {
     return cb > C ? C : cb;
 }
 
-// Pass 1: per-(n, slab, group) sum and sum of squares.  part[((n*S + s)*G + g)*2 + {0,1}]
+// Merge of two (count, mean, M2) summaries (Chan et al.): exact up to rounding whatever |mean| / std is,
+// unlike E[x^2] - mean^2 (a VAE group spans up to 4 M elements with eps = 1e-6).
+__device__ __forceinline__ void chan_merge(float& nA, float& mA, float& qA, float nB, float mB, float qB) {
+    if (nB <= 0.f) return;
+    const float n = nA + nB;
+    const float d = mB - mA;
+    const float f = nB / n;
+    mA += d * f;
+    qA += qB + d * d * nA * f;
+    nA = n;
+}
+
+// Pass 1: per-(n, slab, group) statistics as (mean, M2 = sum (x - mean)^2) of the slab's
+// rows_per x channels-per-group elements:  part[((n*S + s)*G + g)*2 + {0,1}].  Each thread accumulates
+// its pixels per channel SHIFTED by the first value it sees for that channel (sums of x - x0 and their
+// squares cancel nothing even when |mean| >> std); thread, channel and slab summaries are then merged
+// with chan_merge in a fixed order.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, long ldx,
                                                        float* __restrict__ part, long HW, int C,
                                                        int G, int S, int CB) {
     __shared__ float red[256 * 16];
+    __shared__ float rcnt[256];
     __shared__ float chan[GN_MAX_CB * 2];
     const int n = blockIdx.z, s = blockIdx.y, cb = blockIdx.x;
     const int tid = threadIdx.x;
@@ -40,12 +57,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     const long p0 = (long)s * rows_per;
     long p1 = p0 + rows_per;
     if (p1 > HW) p1 = HW;
-    float sm[8], sq[8];
+    float sm[8], sq[8], piv[8];
+    float cnt = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
-    if (prow < rows_par) {
+    for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; piv[e] = 0.f; }
+    if (prow < rows_par && p0 + prow < p1) {
         const half_t* base = x + ((long)n * HW) * ldx + c0 + cc_l * 8;
         long pix = p0 + prow;
+        {
+            const h8 v0 = *reinterpret_cast<const h8*>(base + pix * ldx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) piv[e] = (float)v0[e];
+        }
         // eight independent 16-byte loads in flight per thread (HBM latency, not VALU, is the limit)
         for (; pix + 7L * rows_par < p1; pix += 8L * rows_par) {
             h8 v[8];
@@ -54,35 +77,78 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
 #pragma unroll
             for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e]; sm[e] += f; sq[e] += f * f; }
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[u][e] - piv[e]; sm[e] += f; sq[e] += f * f; }
+            cnt += 8.f;
         }
         for (; pix < p1; pix += rows_par) {
             const h8 v = *reinterpret_cast<const h8*>(base + pix * ldx);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sm[e] += f; sq[e] += f * f; }
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e] - piv[e]; sm[e] += f; sq[e] += f * f; }
+            cnt += 1.f;
         }
     }
+    // thread summary per channel: mean = pivot + S1 / n, M2 = S2 - S1^2 / n
+    const float icnt = cnt > 0.f ? 1.0f / cnt : 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = sm[e]; red[tid * 16 + 8 + e] = sq[e]; }
+    for (int e = 0; e < 8; ++e) {
+        const float d = sm[e] * icnt;
+        red[tid * 16 + e] = piv[e] + d;
+        red[tid * 16 + 8 + e] = sq[e] - sm[e] * d;
+    }
+    rcnt[tid] = cnt;
     __syncthreads();
-    // fixed-order reduction over the pixel-parallel rows -> per-channel sums in LDS
+    // fixed-order merge over the pixel-parallel rows -> per-channel (mean, M2) in LDS
+    float ctot = 0.f;
     if (prow == 0) {
-        for (int r = 1; r < rows_par; ++r) {
-            const int o = (r * ccb + cc_l) * 16;
+        float mA[8], qA[8];
+        float nA = cnt;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sm[e] += red[o + e]; sq[e] += red[o + 8 + e]; }
+        for (int e = 0; e < 8; ++e) { mA[e] = red[tid * 16 + e]; qA[e] = red[tid * 16 + 8 + e]; }
+        for (int r = 1; r < rows_par; ++r) {
+            const int t = r * ccb + cc_l;
+            const float nB = rcnt[t];
+            float nn = nA;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { nn = nA; chan_merge(nn, mA[e], qA[e], nB, red[t * 16 + e], red[t * 16 + 8 + e]); }
+            nA = nn;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { chan[(cc_l * 8 + e) * 2] = sm[e]; chan[(cc_l * 8 + e) * 2 + 1] = sq[e]; }
+        for (int e = 0; e < 8; ++e) { chan[(cc_l * 8 + e) * 2] = mA[e]; chan[(cc_l * 8 + e) * 2 + 1] = qA[e]; }
+        ctot = nA;
     }
     __syncthreads();
     const int cpg = C / G;
     const int ng = cw / cpg;
     if (tid < ng) {
-        float a = 0.f, b = 0.f;
-        for (int c = 0; c < cpg; ++c) { a += chan[(tid * cpg + c) * 2]; b += chan[(tid * cpg + c) * 2 + 1]; }
+        const float per = (float)(p1 - p0);          // every channel of the slab saw p1 - p0 pixels
+        float nA = per, mA = chan[(tid * cpg) * 2], qA = chan[(tid * cpg) * 2 + 1];
+        for (int c = 1; c < cpg; ++c) chan_merge(nA, mA, qA, per, chan[(tid * cpg + c) * 2], chan[(tid * cpg + c) * 2 + 1]);
         float* dst = part + (((long)n * S + s) * G + c0 / cpg + tid) * 2;
-        dst[0] = a; dst[1] = b;
+        dst[0] = mA; dst[1] = qA;
+    }
+    (void)ctot;
+}
+
+// Merges the S slab summaries of every (sample, group) into one (S' = 1 form of `part`): used ahead of the
+// apply pass when a producing convolution wrote one summary per 256-pixel tile (up to 1024 per image at
+// 512 x 512), which would be too many for every apply block to merge in its prologue.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int S,
+                                                          int G, long rows_per, long HW, int cpg) {
+    __shared__ float rn[256], rm[256], rq[256];
+    const int n = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    float nA = 0.f, mA = 0.f, qA = 0.f;
+    for (int k = tid; k < S; k += 256) {
+        long rows = HW - (long)k * rows_per;
+        if (rows > rows_per) rows = rows_per;
+        const float2 v = *reinterpret_cast<const float2*>(part + (((long)n * S + k) * G + g) * 2);
+        chan_merge(nA, mA, qA, (float)rows * (float)cpg, v.x, v.y);
+    }
+    rn[tid] = nA; rm[tid] = mA; rq[tid] = qA;
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 256 && k < S; ++k) chan_merge(nA, mA, qA, rn[k], rm[k], rq[k]);
+        float* dst = out + ((long)n * G + g) * 2;
+        dst[0] = mA; dst[1] = qA;
     }
 }
 
@@ -96,12 +162,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        half_t* __restrict__ y, long ldy, long HW,
-                                                       int C, int G, int S, int rows_per, float eps, int silu) {
+                                                       int C, int G, int S, long stat_rows, int rows_per, float eps,
+                                                       int silu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = reinterpret_cast<float*>(smem);  // [C] scale
     float* sh = sc + C;                          // [C] shift
     float* st = sh + C;                          // [G][2] mean, rstd
-    float* red = st + 2 * G;                     // [256 / G][G][2]
+    float* red = st + 2 * G;                     // [256 / G][G][3]
     const int n = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / G;
     const int CC = C >> 3;
@@ -125,29 +192,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
             }
         }
     }
-    // slab partials -> mean / rstd: 256 / G threads per group sum interleaved slabs, then thread g
-    // adds those partial sums in order
+    // slab summaries (mean, M2) -> mean / rstd: 256 / G threads per group merge interleaved slabs, then
+    // thread g merges those in order (chan_merge: fixed order, no cancellation)
     const int parts = 256 / G;
     {
         const int g = tid % G, part_i = tid / G;
         if (part_i < parts) {
-            float a = 0.f, b = 0.f;
+            float nA = 0.f, mA = 0.f, qA = 0.f;
             const float* src = part + ((long)n * S * G + g) * 2;
-            for (int k = part_i; k < S; k += parts) { a += src[(long)k * G * 2]; b += src[(long)k * G * 2 + 1]; }
-            red[(part_i * G + g) * 2] = a;
-            red[(part_i * G + g) * 2 + 1] = b;
+            for (int k = part_i; k < S; k += parts) {
+                long rows = HW - (long)k * stat_rows;
+                if (rows > stat_rows) rows = stat_rows;
+                chan_merge(nA, mA, qA, (float)rows * (float)cpg, src[(long)k * G * 2], src[(long)k * G * 2 + 1]);
+            }
+            red[(part_i * G + g) * 3] = nA;
+            red[(part_i * G + g) * 3 + 1] = mA;
+            red[(part_i * G + g) * 3 + 2] = qA;
         }
     }
     __syncthreads();
     if (tid < G) {
-        float a = 0.f, b = 0.f;
-        for (int k = 0; k < parts; ++k) { a += red[(k * G + tid) * 2]; b += red[(k * G + tid) * 2 + 1]; }
-        const float cnt = (float)HW * (float)cpg;
-        const float mean = a / cnt;
-        float var = b / cnt - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        st[tid * 2] = mean;
-        st[tid * 2 + 1] = rsqrtf(var + eps);
+        float nA = red[tid * 3], mA = red[tid * 3 + 1], qA = red[tid * 3 + 2];
+        for (int k = 1; k < parts; ++k) chan_merge(nA, mA, qA, red[(k * G + tid) * 3], red[(k * G + tid) * 3 + 1], red[(k * G + tid) * 3 + 2]);
+        const float var = qA / ((float)HW * (float)cpg);
+        st[tid * 2] = mA;
+        st[tid * 2 + 1] = rsqrtf((var < 0.f ? 0.f : var) + eps);
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -186,8 +255,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 // The block's whole [HW x unit] panel stays in registers between the statistics and the apply:
 // x is read once, y written once, one launch instead of two (the 2-launch form is latency-bound
 // here: 10-17 us for tensors an HBM pass moves in 2-5 us).  Thread t owns channel chunk t % UC of
-// pixels t / UC + k * PL, so its 8 scale/shift pairs are loop invariants.  Variance is centred
-// (second reduction over the registers).  Reductions run in a fixed order: bitwise reproducible.
+// pixels t / UC + k * PL, so its 8 scale/shift pairs are loop invariants.  Variance is centred: a
+// second reduction over the registers, sum (x - mean)^2.  Reductions run in a fixed order: bitwise
+// reproducible.
 template <int T, int NV>
 __global__ __launch_bounds__(T) void gn_fused_kernel(const half_t* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
@@ -212,9 +282,11 @@ __global__ __launch_bounds__(T) void gn_fused_kernel(const half_t* __restrict__ 
         if (active && p < HW) v[k] = *reinterpret_cast<const h8*>(xb + (long)p * ldx);
         else v[k] = h8{0, 0, 0, 0, 0, 0, 0, 0};
     }
-    // per-thread sums per channel pair: v_dot2_f32_f16 against (1,1) and against itself (zero-filled
-    // slots add nothing, so no guards here)
-    float s2[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+    // Two passes over the register-resident panel: group means first, then sum (x - mean)^2 -- exact
+    // whatever |mean| / std is (the E[x^2] - mean^2 form of round 1 lost the variance to cancellation
+    // for |mean| >> std).  Per-thread sums per channel pair with v_dot2_f32_f16 against (1,1);
+    // zero-filled slots add nothing to the sums and are masked out of the squares.
+    float s2[4] = {0.f, 0.f, 0.f, 0.f};
     const h2 ones = {(half_t)1.f, (half_t)1.f};
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -223,45 +295,55 @@ __global__ __launch_bounds__(T) void gn_fused_kernel(const half_t* __restrict__ 
             for (int j = 0; j < 4; ++j) {
                 const h2 pr = {v[k][2 * j], v[k][2 * j + 1]};
                 s2[j] = __builtin_amdgcn_fdot2(pr, ones, s2[j], false);
-                q2[j] = __builtin_amdgcn_fdot2(pr, pr, q2[j], false);
             }
         }
     }
-    float a = 0.f, b = 0.f, aq = 0.f, bq = 0.f;      // sums / sums of squares for gA and gA + 1
+    // block reduction in a fixed order: lanes (xor tree), then waves (serial)
+    auto block_reduce4 = [&](float a, float b, float* dst4) {
+        float r[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float t = (g == gA ? a : 0.f) + (g == gA + 1 ? b : 0.f);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            r[g] = t;
+        }
+        __syncthreads();                             // wred free again (second use)
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wred[tid >> 6][g] = r[g];
+        }
+        __syncthreads();
+        if (tid < 4) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += wred[w][tid];
+            dst4[tid] = t;
+        }
+        __syncthreads();
+    };
+    float a = 0.f, b = 0.f;                          // sums for gA and gA + 1
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (2 * j < split) { a += s2[j]; aq += q2[j]; } else { b += s2[j]; bq += q2[j]; }
+        if (2 * j < split) a += s2[j]; else b += s2[j];
     }
-    // block reduction in a fixed order: lanes (xor tree), then waves (serial)
-    float r[8];
+    const float cnt = (float)HW * (float)cpg;
+    block_reduce4(a, b, stat);
+    const float mA = stat[gA & 3] / cnt, mB = stat[(gA + 1) & 3] / cnt;
+    float qa = 0.f, qb = 0.f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float t = (g == gA ? a : 0.f) + (g == gA + 1 ? b : 0.f);
-        float u = (g == gA ? aq : 0.f) + (g == gA + 1 ? bq : 0.f);
+    for (int k = 0; k < NV; ++k) {
+        if (k * PL < HW && active && plane + k * PL < HW) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off); u += __shfl_xor(u, off); }
-        r[g] = t;
-        r[4 + g] = u;
+            for (int e = 0; e < 8; ++e) {
+                const float dlt = (float)v[k][e] - (e < split ? mA : mB);
+                if (e < split) qa += dlt * dlt; else qb += dlt * dlt;
+            }
+        }
     }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int g = 0; g < 8; ++g) wred[tid >> 6][g] = r[g];
-    }
-    __syncthreads();
-    if (tid < 4) {
-        float t = 0.f, u = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) { t += wred[w][tid]; u += wred[w][4 + tid]; }
-        const float cnt = (float)HW * (float)cpg;
-        const float mean = t / cnt;
-        float var = u / cnt - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        stat[tid] = mean;
-        stat[4 + tid] = rsqrtf(var + eps);
-    }
-    __syncthreads();
+    block_reduce4(qa, qb, stat + 4);
     if (!active) return;
-    const float mA = stat[gA & 3], mB = stat[(gA + 1) & 3], rA = stat[4 + (gA & 3)], rB = stat[4 + ((gA + 1) & 3)];
+    const float rA = rsqrtf(stat[4 + (gA & 3)] / cnt + eps), rB = rsqrtf(stat[4 + ((gA + 1) & 3)] / cnt + eps);
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -357,6 +439,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
+// Per-row sum and sum of squares (one wave per row): the stand-alone producer of the LayerNorm
+// statistics for tensors whose GEMM could not emit them from its epilogue (split-K launches).
+__global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, long ldx, float* __restrict__ stat,
+                                                        long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int CC = C >> 3;
+    float sm = 0.f, sq = 0.f;
+    for (int cc = lane; cc < CC; cc += 64) {
+        const h8 v = *reinterpret_cast<const h8*>(x + row * ldx + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; sm += f; sq += f * f; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); sq += __shfl_xor(sq, off); }
+    if (lane == 0) { stat[row * 2] = sm; stat[row * 2 + 1] = sq; }
+}
+
 int gn_slabs(int N, long HW, int C, int G) {
     // aim for ~1024 stats blocks, at least 64 pixels per slab, at most 256 slabs
     const int cblocks = cdiv(C, gn_block_channels(C, G));
@@ -374,9 +475,11 @@ long gn_scratch_floats(int N, long HW, int C, int G) {
     return (long)N * gn_slabs(N, HW, C, G) * G * 2;
 }
 
+bool gn_wants_stats(long HW, int C, int G) { return gn_fused_unit(HW, C, G) == 0; }
+
 int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y,
                      long ldy, int N, long HW, int C, int G, float eps, int silu, float* scratch,
-                     hipStream_t s) {
+                     hipStream_t s, const GnStats* pre) {
     if (C % 8 != 0 || C % G != 0 || G > 256) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
     if (const int U = gn_fused_unit(HW, C, G)) {
         const dim3 grid(C / U, N);
@@ -390,9 +493,23 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
         SD_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    const int S = gn_slabs(N, HW, C, G);
-    const int CB = gn_block_channels(C, G);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
+    int S = gn_slabs(N, HW, C, G);
+    long stat_rows = (HW + S - 1) / S;
+    const float* part = scratch;
+    if (pre && pre->part) {
+        // the producing convolution's epilogue already wrote one (mean, M2) summary per tile of
+        // pre->rows pixels: no statistics pass over x.  Many tiles per image are merged once, by a small
+        // kernel, instead of by every apply block.
+        part = pre->part; S = pre->S; stat_rows = pre->rows;
+        if (S > 64) {
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, s, part, scratch, S, G, stat_rows, HW, C / G);
+            SD_HIP_CHECK(hipGetLastError());
+            part = scratch; S = 1; stat_rows = HW;
+        }
+    } else {
+        const int CB = gn_block_channels(C, G);
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
+    }
     // apply: rows per block so that a thread holds <= GN_APPLY_NV chunks, and >= ~512 blocks overall
     const int CC = C / 8;
     long rows_per = (long)256 * GN_APPLY_NV / CC;
@@ -400,8 +517,8 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
     const long want = cdiv(HW * N, 512);
     if (rows_per > want) rows_per = want > 0 ? want : 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)cdiv(HW, rows_per), N), dim3(256),
-                       ((size_t)C * 2 + (size_t)G * 2 + 512) * sizeof(float), s,
-                       x, ldx, scratch, gamma, beta, y, ldy, HW, C, G, S, (int)rows_per, eps, silu);
+                       ((size_t)C * 2 + (size_t)G * 2 + 768) * sizeof(float), s,
+                       x, ldx, part, gamma, beta, y, ldy, HW, C, G, S, stat_rows, (int)rows_per, eps, silu);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -411,6 +528,13 @@ int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float*
     if (C % 8 != 0 || C > 64 * 8 * LN_MAX) { set_error("layernorm: unsupported C"); return 1; }
     hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy,
                        rows, C, eps);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_row_stats(const half_t* x, long ldx, float* stat, long rows, int C, hipStream_t s) {
+    if (C % 8 != 0) { set_error("row_stats: C must be a multiple of 8"); return 1; }
+    hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, stat, rows, C);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

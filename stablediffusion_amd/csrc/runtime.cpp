@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace sd {
@@ -241,6 +242,20 @@ int WeightStore::pack_norm(const std::string& prefix, NormW* out) {
     return 0;
 }
 
+int WeightStore::fold_ln(ConvW* w, const NormW& ln, int rows_scaled, float row_scale) {
+    if (ln.C != w->K || w->ks != 1) { set_error("fold_ln: LayerNorm width must equal the linear's K"); return 1; }
+    const long padded = round_up(w->cout, kWeightRowPad);
+    float* nb = static_cast<float*>(dmalloc((size_t)padded * sizeof(float)));
+    w->wsum = static_cast<float*>(dmalloc((size_t)padded * sizeof(float)));
+    if (!nb || !w->wsum) { set_error("hipMalloc failed (fold_ln)"); return 3; }
+    SD_HIP_CHECK(hipMemsetAsync(nb, 0, (size_t)padded * sizeof(float), 0));
+    SD_HIP_CHECK(hipMemsetAsync(w->wsum, 0, (size_t)padded * sizeof(float), 0));
+    int rc = launch_ln_fold(w->w, w->K, w->cout, ln.gamma, ln.beta, w->bias, nb, w->wsum, rows_scaled, row_scale, 0);
+    if (rc) return rc;
+    w->bias = nb;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------- profiler
 namespace {
 struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
@@ -274,9 +289,31 @@ int prof_collect(std::map<std::string, ProfAgg>* out) {
     return 0;
 }
 
+void ctx_gnpool_init(Ctx& c, int N, long HW_max, int G) {
+    static const bool off = getenv("SD_NO_GN_EPILOGUE") != nullptr;    // A/B switch: GroupNorm runs its own statistics pass
+    c.gn_groups = G;
+    c.gn_next = 0;
+    for (int i = 0; i < Ctx::kGnPool; ++i) {
+        c.gnpool[i].buf = off ? nullptr : c.arena->alloc_f(gnstat_floats(N, HW_max, G));
+        c.gnpool[i].st = GnStats();
+    }
+}
+
+GnStatBuf* ctx_gnbuf(Ctx& c) {
+    if (!c.gnpool[0].buf) return nullptr;
+    GnStatBuf* b = &c.gnpool[c.gn_next];
+    c.gn_next = (c.gn_next + 1) % Ctx::kGnPool;
+    b->st = GnStats();
+    return b;
+}
+
 // -------------------------------------------------------------------------------------------- ops
 void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int stride, int up,
-             const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad, int act) {
+             const float* rowadd, int rowadd_ld, const View* res, int geglu, int pad, int act, const ConvFuse* fuse) {
+    const RowStat* ln_in = fuse ? fuse->ln_in : nullptr;
+    const float ln_eps = fuse ? fuse->ln_eps : 0.f;
+    RowStat* stat_out = fuse ? fuse->stat_out : nullptr;
+    GnStatBuf* gn_out = fuse ? fuse->gn_out : nullptr;
     IGemmParams p;
     p.x = x.p; p.ldx = x.ld;
     p.w = w.w; p.bias = w.bias;
@@ -301,7 +338,30 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
     p.K = (int)w.K;
     p.geglu = geglu;
     p.act = act;
+    if (ln_in) {
+        if (!w.wsum) { set_error("op_conv: LayerNorm statistics passed to a linear without folded weights"); c.err = 1; return; }
+        p.ln_stat = ln_in->p; p.ln_parts = ln_in->parts; p.ln_C = (int)w.K; p.ln_eps = ln_eps; p.ln_wsum = w.wsum;
+    }
     const bool v2 = igemm2_supported(p);
+    if (ln_in && !v2) { set_error("op_conv: the LayerNorm fold needs the LDS-DMA kernel"); c.err = 1; return; }
+    bool own_stats = false;      // the GEMM's epilogue writes the row statistics itself
+    if (stat_out) {
+        int parts = 1;
+        own_stats = igemm2_emits_rowstats(p, &parts);
+        stat_out->parts = own_stats ? parts : 1;
+        if (own_stats) p.rowstat_out = stat_out->p;
+    }
+    if (gn_out) {
+        int rows = 0;
+        gn_out->st = GnStats();
+        if (gn_out->buf && igemm2_emits_gnstats(p, fuse->gn_groups, &rows)) {
+            p.gnstat_out = gn_out->buf;
+            p.gn_groups = fuse->gn_groups;
+            gn_out->st.part = gn_out->buf;
+            gn_out->st.rows = rows;
+            gn_out->st.S = p.OH * p.OW / rows;
+        }
+    }
     if (act && !v2) { set_error("op_conv: activation epilogue needs the LDS-DMA kernel (Cin % 64, Cout % 8)"); c.err = 1; return; }
     float* partial = nullptr;
     if (v2) {
@@ -330,13 +390,23 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
     }
     c.err = v2 ? launch_igemm2(p, partial, c.stream) : launch_igemm(p, c.stream);
     prof_close(c.stream);
+    if (stat_out && !own_stats && !c.err) {
+        prof_open(c.stream, "row_stats_kernel", 0.0, 2.0 * p.M * w.cout);
+        c.err = launch_row_stats(y.p, y.ld, stat_out->p, p.M, w.cout, c.stream);
+        prof_close(c.stream);
+    }
 }
 
-void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu) {
+void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu,
+                  const GnStatBuf* pre) {
     float* scratch = c.arena->alloc_f(gn_scratch_floats(N, HW, n.C, G));
     if (c.dry || c.err) return;
-    prof_open(c.stream, "groupnorm(stats+apply)", 0.0, 4.0 * N * HW * n.C);
-    c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream);
+    const GnStats* st = (pre && pre->st.part && gn_wants_stats(HW, n.C, G)) ? &pre->st : nullptr;
+    // bytes really moved: the single-kernel form and the apply pass read x and write y; only the
+    // stand-alone statistics pass reads x once more
+    const bool own_pass = gn_wants_stats(HW, n.C, G) && !st;
+    prof_open(c.stream, own_pass ? "groupnorm(stats+apply)" : "groupnorm(apply)", 0.0, (own_pass ? 6.0 : 4.0) * N * HW * n.C);
+    c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream, st);
     prof_close(c.stream);
 }
 

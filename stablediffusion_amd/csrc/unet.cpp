@@ -8,6 +8,7 @@
 // stacked GEMV for all 22 time_emb_proj layers, and a stack-discipline workspace arena.
 #include "model.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace sd {
 
@@ -166,11 +167,7 @@ int UNet::pack_xformer(const std::string& p, Xformer* x, int heads, int depth) {
         // fold softmax's log2(e)/sqrt(d) into both query projections (rows [0, C) of the fused q|k|v
         // matrix and all of attn2.to_q; neither has a bias): the attention kernel then runs its
         // `prescaled` path.  One extra fp16 rounding of weights that were fp16-rounded already.
-        {
-            const float qs = 1.4426950408889634f / sqrtf((float)(x->C / heads));
-            if ((rc = launch_scale_f16(b.qkv.w, (long)x->C * b.qkv.K, qs, 0))) return rc;
-            if ((rc = launch_scale_f16(b.q2.w, (long)x->C * b.q2.K, qs, 0))) return rc;
-        }
+        const float qs = 1.4426950408889634f / sqrtf((float)(x->C / heads));
         // text K/V projections depend only on encoder_hidden_states: all of them are stacked into
         // one GEMM (kv_all) issued once per forward instead of one small launch per block
         b.kv_off = kv_total;
@@ -180,6 +177,20 @@ int UNet::pack_xformer(const std::string& p, Xformer* x, int heads, int depth) {
         if ((rc = ws.pack_conv(q + ".attn2.to_out.0", &b.out2))) return rc;
         if ((rc = ws.pack_geglu(q + ".ff.net.0.proj", &b.ff1))) return rc;
         if ((rc = ws.pack_conv(q + ".ff.net.2", &b.ff2))) return rc;
+        // The three LayerNorms feed one linear each (norm1 -> q|k|v, norm2 -> attn2.to_q, norm3 -> the GEGLU
+        // projection): their affine is folded into those weights here and their statistics come out of the
+        // epilogue of the GEMM that produces the normalised tensor, so a forward launches no LayerNorm
+        // kernel (48 launches, 0.55 ms of the C2 forward in round 1).  SD_NO_LN_FOLD=1 keeps the kernels.
+        static const bool no_fold = getenv("SD_NO_LN_FOLD") != nullptr;
+        b.fold = !no_fold;
+        if (b.fold) {
+            if ((rc = ws.fold_ln(&b.qkv, b.ln1, x->C, qs))) return rc;
+            if ((rc = ws.fold_ln(&b.q2, b.ln2, x->C, qs))) return rc;
+            if ((rc = ws.fold_ln(&b.ff1, b.ln3, 0, 1.0f))) return rc;
+        } else {
+            if ((rc = launch_scale_f16(b.qkv.w, (long)x->C * b.qkv.K, qs, 0))) return rc;
+            if ((rc = launch_scale_f16(b.q2.w, (long)x->C * b.q2.K, qs, 0))) return rc;
+        }
     }
     return 0;
 }
@@ -243,60 +254,101 @@ int UNet::finalize() {
 
 // ------------------------------------------------------------------------------------------ blocks
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
-                const float* tproj, int tproj_ld) {
+                const float* tproj, int tproj_ld, const GnStatBuf* x_stats, GnStatBuf** out_stats) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const long M = (long)N * H * W;
+    const long HW = (long)H * W;
     View h1(a.alloc_h(M * r.cin), r.cin, r.cin);
-    op_groupnorm(c, r.n1, x, h1, N, (long)H * W, G, eps, 1);
+    op_groupnorm(c, r.n1, x, h1, N, HW, G, eps, 1, x_stats);
     View h2(a.alloc_h(M * r.cout), r.cout, r.cout);
-    op_conv(c, r.c1, h1, N, H, W, h2, 1, 0, tproj ? tproj + r.temb_off : nullptr, tproj_ld);
+    // conv1's epilogue leaves the GroupNorm summaries of h2 for norm2 (big maps only: the small ones are
+    // normalised by the single-kernel form, which reads x once anyway)
+    ConvFuse f1;
+    f1.gn_out = gn_wants_stats(HW, r.cout, G) ? ctx_gnbuf(c) : nullptr;
+    f1.gn_groups = G;
+    op_conv(c, r.c1, h1, N, H, W, h2, 1, 0, tproj ? tproj + r.temb_off : nullptr, tproj_ld, nullptr, 0, -1, 0, &f1);
     View h3(a.alloc_h(M * r.cout), r.cout, r.cout);
-    op_groupnorm(c, r.n2, h2, h3, N, (long)H * W, G, eps, 1);
+    op_groupnorm(c, r.n2, h2, h3, N, HW, G, eps, 1, f1.gn_out);
     View res = x;
     if (r.has_sc) {
         res = View(a.alloc_h(M * r.cout), r.cout, r.cout);
         op_conv(c, r.sc, x, N, H, W, res);
     }
-    op_conv(c, r.c2, h3, N, H, W, out, 1, 0, nullptr, 0, &res);
+    ConvFuse f2;
+    f2.gn_out = (out_stats && gn_wants_stats(HW, r.cout, G)) ? ctx_gnbuf(c) : nullptr;
+    f2.gn_groups = G;
+    op_conv(c, r.c2, h3, N, H, W, out, 1, 0, nullptr, 0, &res, 0, -1, 0, &f2);
+    if (out_stats) *out_stats = f2.gn_out;
     a.release(mk);
 }
 
-void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L) {
+void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L,
+                 const GnStatBuf* x_stats, GnStatBuf** out_stats) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const int C = t.C;
     const int T = H * W;
     const long M = (long)N * T;
     const int d = C / t.heads;
+    const bool fold = !t.blocks.empty() && t.blocks[0].fold;
     View hn(a.alloc_h(M * C), C, C);
-    op_groupnorm(c, t.gn, x, hn, N, T, G, 1e-6f, 0);
+    op_groupnorm(c, t.gn, x, hn, N, T, G, 1e-6f, 0, x_stats);
     View cur(a.alloc_h(M * C), C, C), nxt(a.alloc_h(M * C), C, C);
-    op_conv(c, t.pin, hn, N, H, W, cur);
-    for (const TBlock& b : t.blocks) {
+    // row statistics of the residual stream at the three LayerNorm sites (cur -> ln1, t2 -> ln2, t3 -> ln3)
+    RowStat st_cur, st_t2, st_t3;
+    if (fold) {
+        st_cur.p = a.alloc_f(rowstat_floats(M, C));
+        st_t2.p = a.alloc_f(rowstat_floats(M, C));
+        st_t3.p = a.alloc_f(rowstat_floats(M, C));
+    }
+    ConvFuse f_cur, f_t2, f_t3, f_ln1, f_ln2, f_ln3;          // producers of / consumers at the three LayerNorm sites
+    f_cur.stat_out = &st_cur; f_t2.stat_out = &st_t2; f_t3.stat_out = &st_t3;
+    f_ln1.ln_in = &st_cur; f_ln2.ln_in = &st_t2; f_ln3.ln_in = &st_t3;
+    f_ln1.ln_eps = f_ln2.ln_eps = f_ln3.ln_eps = 1e-5f;
+    op_conv(c, t.pin, hn, N, H, W, cur, 1, 0, nullptr, 0, nullptr, 0, -1, 0, fold ? &f_cur : nullptr);
+    for (size_t bi = 0; bi < t.blocks.size(); ++bi) {
+        const TBlock& b = t.blocks[bi];
+        const bool more = bi + 1 < t.blocks.size();
         const size_t mb = a.mark();
-        View n(a.alloc_h(M * C), C, C);
-        op_layernorm(c, b.ln1, cur, n, M, 1e-5f);
+        View n(fold ? nullptr : a.alloc_h(M * C), C, C);
         View qkv(a.alloc_h(M * 3 * C), 3 * C, 3 * C);
-        op_conv(c, b.qkv, n, N, H, W, qkv);
+        if (fold) {
+            op_conv(c, b.qkv, cur, N, H, W, qkv, 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f_ln1);
+        } else {
+            op_layernorm(c, b.ln1, cur, n, M, 1e-5f);
+            op_conv(c, b.qkv, n, N, H, W, qkv);
+        }
         View att(a.alloc_h(M * C), C, C);
         op_attention(c, qkv.slice(0, C), qkv.slice(C, C), qkv.slice(2 * C, C), att, N, T, T, t.heads, d, 0, 1);
         View t2(a.alloc_h(M * C), C, C);
-        op_conv(c, b.out1, att, N, H, W, t2, 1, 0, nullptr, 0, &cur);
-        op_layernorm(c, b.ln2, t2, n, M, 1e-5f);
+        op_conv(c, b.out1, att, N, H, W, t2, 1, 0, nullptr, 0, &cur, 0, -1, 0, fold ? &f_t2 : nullptr);
         View q(a.alloc_h(M * C), C, C);
-        op_conv(c, b.q2, n, N, H, W, q);
+        if (fold) {
+            op_conv(c, b.q2, t2, N, H, W, q, 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f_ln2);
+        } else {
+            op_layernorm(c, b.ln2, t2, n, M, 1e-5f);
+            op_conv(c, b.q2, n, N, H, W, q);
+        }
         op_attention(c, q, text_kv.slice(b.kv_off, C), text_kv.slice(b.kv_off + C, C), att, N, T, L, t.heads, d, 0, 1);
         View t3(a.alloc_h(M * C), C, C);
-        op_conv(c, b.out2, att, N, H, W, t3, 1, 0, nullptr, 0, &t2);
-        op_layernorm(c, b.ln3, t3, n, M, 1e-5f);
+        op_conv(c, b.out2, att, N, H, W, t3, 1, 0, nullptr, 0, &t2, 0, -1, 0, fold ? &f_t3 : nullptr);
         View g(a.alloc_h(M * 4 * C), 4 * C, 4 * C);
-        op_conv(c, b.ff1, n, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1);
-        op_conv(c, b.ff2, g, N, H, W, nxt, 1, 0, nullptr, 0, &t3);
+        if (fold) {
+            op_conv(c, b.ff1, t3, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1, -1, 0, &f_ln3);
+        } else {
+            op_layernorm(c, b.ln3, t3, n, M, 1e-5f);
+            op_conv(c, b.ff1, n, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1);
+        }
+        op_conv(c, b.ff2, g, N, H, W, nxt, 1, 0, nullptr, 0, &t3, 0, -1, 0, (fold && more) ? &f_cur : nullptr);
         a.release(mb);
         View tmp = cur; cur = nxt; nxt = tmp;
     }
-    op_conv(c, t.pout, cur, N, H, W, out, 1, 0, nullptr, 0, &x);
+    ConvFuse fo;
+    fo.gn_out = (out_stats && gn_wants_stats(T, C, G)) ? ctx_gnbuf(c) : nullptr;
+    fo.gn_groups = G;
+    op_conv(c, t.pout, cur, N, H, W, out, 1, 0, nullptr, 0, &x, 0, -1, 0, &fo);
+    if (out_stats) *out_stats = fo.gn_out;
     a.release(mk);
 }
 
@@ -386,6 +438,11 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         return View(ct.p + ct.c1, ct.c1 + ct.c2, ct.c2);
     };
 
+    // ---- GroupNorm summaries travel from the convolution that writes a tensor to the GroupNorm that reads
+    //      it (big maps only); `xs` = those of the current x, nullptr when nobody produced them ----
+    ctx_gnpool_init(c, B, (long)H * W, G);
+    GnStatBuf* xs = nullptr;
+
     // ---- conv_in (Cin = 4: im2col into a 64-wide K, then the GEMM kernel) ----
     int h = H, w = W;
     {
@@ -394,7 +451,11 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         half_t* col = a.alloc_h(M * conv_in.K);
         if (go && !c.err) c.err = launch_im2col_nchw3x3(sample, col, B, cfg.in_channels, H, W, (int)conv_in.K, s);
         ConvW pw = conv_in; pw.ks = 1;
-        op_conv(c, pw, View(col, conv_in.K, (int)conv_in.K), B, H, W, skip_view(skip_i));
+        ConvFuse f;
+        f.gn_out = gn_wants_stats((long)H * W, boc[0], G) ? ctx_gnbuf(c) : nullptr;
+        f.gn_groups = G;
+        op_conv(c, pw, View(col, conv_in.K, (int)conv_in.K), B, H, W, skip_view(skip_i), 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
+        xs = f.gn_out;
         a.release(mk);
     }
     View x = skip_view(skip_i++);
@@ -406,21 +467,26 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
             if (cfg.down_block_has_attn[i]) {
                 const size_t mk = a.mark();
                 View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
-                run_resnet(c, r, x, B, h, w, tmp, G, eps, tproj, temb_total);
+                GnStatBuf* rs = nullptr;
+                run_resnet(c, r, x, B, h, w, tmp, G, eps, tproj, temb_total, xs, &rs);
                 View dst = skip_view(skip_i);
-                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, text_kv, L);
+                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, &xs);
                 a.release(mk);
                 x = dst;
             } else {
                 View dst = skip_view(skip_i);
-                run_resnet(c, r, x, B, h, w, dst, G, eps, tproj, temb_total);
+                run_resnet(c, r, x, B, h, w, dst, G, eps, tproj, temb_total, xs, &xs);
                 x = dst;
             }
             ++skip_i;
         }
         if (i != nb - 1) {
             View dst = skip_view(skip_i++);
-            op_conv(c, down_ds[i], x, B, h, w, dst, 2, 0);
+            ConvFuse f;
+            f.gn_out = gn_wants_stats((long)(h / 2) * (w / 2), down_ds[i].cout, G) ? ctx_gnbuf(c) : nullptr;
+            f.gn_groups = G;
+            op_conv(c, down_ds[i], x, B, h, w, dst, 2, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
+            xs = f.gn_out;
             h /= 2; w /= 2;
             x = dst;
         }
@@ -431,11 +497,12 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         const int C = boc[nb - 1];
         const long M = (long)B * h * w;
         View m0(a.alloc_h(M * C), C, C), m1(a.alloc_h(M * C), C, C);
-        run_resnet(c, mid_r0, x, B, h, w, m0, G, eps, tproj, temb_total);
-        run_xformer(c, mid_att, m0, B, h, w, m1, G, text_kv, L);
+        GnStatBuf *s0 = nullptr, *s1 = nullptr;
+        run_resnet(c, mid_r0, x, B, h, w, m0, G, eps, tproj, temb_total, xs, &s0);
+        run_xformer(c, mid_att, m0, B, h, w, m1, G, text_kv, L, s0, &s1);
         const Cat& ct = cats[0];
         View dst(ct.p, ct.c1 + ct.c2, ct.c1);
-        run_resnet(c, mid_r1, m1, B, h, w, dst, G, eps, tproj, temb_total);
+        run_resnet(c, mid_r1, m1, B, h, w, dst, G, eps, tproj, temb_total, s1);   // output joins a concat: no consumer
     }
 
     // ---- up path ----
@@ -457,12 +524,16 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
             } else {
                 dst = View(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
             }
+            // the input is a concatenation [hidden | skip] written by two producers (its groups can straddle
+            // the seam): norm1 computes its own statistics; the tail's GroupNorm gets the last layer's
+            xs = nullptr;
             if (cfg.up_block_has_attn[i]) {
                 View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
-                run_resnet(c, r, xin, B, h, w, tmp, G, eps, tproj, temb_total);
-                run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L);
+                GnStatBuf* rs = nullptr;
+                run_resnet(c, r, xin, B, h, w, tmp, G, eps, tproj, temb_total, nullptr, &rs);
+                run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, last ? &xs : nullptr);
             } else {
-                run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total);
+                run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total, nullptr, last ? &xs : nullptr);
             }
             if (last) {
                 final_x = dst;   // the temporary stays alive for the tail
@@ -483,7 +554,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         const int C = boc[0];
         const long M = (long)B * h * w;
         View hn(a.alloc_h(M * C), C, C);
-        op_groupnorm(c, norm_out, final_x, hn, B, (long)h * w, G, eps, 1);
+        op_groupnorm(c, norm_out, final_x, hn, B, (long)h * w, G, eps, 1, xs);
         View y(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
         op_conv(c, conv_out, hn, B, h, w, y);
         if (go && !c.err) c.err = launch_nhwc_to_nchw(y.p, y.ld, out, B, (long)h * w, cfg.out_channels, s);

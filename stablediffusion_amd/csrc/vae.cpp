@@ -157,18 +157,23 @@ int VAE::finalize() {
     return 0;
 }
 
-void VAE::run_attn(Ctx& c, const VaeAttn& at, View x, int N, int H, int W, View out) {
+void VAE::run_attn(Ctx& c, const VaeAttn& at, View x, int N, int H, int W, View out, const GnStatBuf* x_stats,
+                   GnStatBuf** out_stats) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const int C = at.C;
     const long M = (long)N * H * W;
     View hn(a.alloc_h(M * C), C, C);
-    op_groupnorm(c, at.gn, x, hn, N, (long)H * W, cfg.norm_num_groups, kVaeEps, 0);
+    op_groupnorm(c, at.gn, x, hn, N, (long)H * W, cfg.norm_num_groups, kVaeEps, 0, x_stats);
     View qkv(a.alloc_h(M * 3 * C), 3 * C, 3 * C);
     op_conv(c, at.qkv, hn, N, H, W, qkv);
     View o(a.alloc_h(M * C), C, C);
     op_attention(c, qkv.slice(0, C), qkv.slice(C, C), qkv.slice(2 * C, C), o, N, H * W, H * W, 1, C);
-    op_conv(c, at.out, o, N, H, W, out, 1, 0, nullptr, 0, &x);
+    ConvFuse fo;
+    fo.gn_out = (out_stats && gn_wants_stats((long)H * W, C, cfg.norm_num_groups)) ? ctx_gnbuf(c) : nullptr;
+    fo.gn_groups = cfg.norm_num_groups;
+    op_conv(c, at.out, o, N, H, W, out, 1, 0, nullptr, 0, &x, 0, -1, 0, &fo);
+    if (out_stats) *out_stats = fo.gn_out;
     a.release(mk);
 }
 
@@ -183,6 +188,14 @@ int VAE::run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w) {
     const int top = boc[nb - 1];
     long M = (long)B * h * w;
 
+    // GroupNorm summaries ride from each convolution's epilogue to the GroupNorm that follows (engine.h)
+    ctx_gnpool_init(c, B, (long)h * w << (2 * (nb - 1)), G);
+    GnStatBuf* xs = nullptr;
+    auto gn_fuse = [&](ConvFuse& f, long HW, int C) {
+        f.gn_out = gn_wants_stats(HW, C, G) ? ctx_gnbuf(c) : nullptr;
+        f.gn_groups = G;
+    };
+
     // post_quant_conv (pointwise on NCHW, 4 channels) + conv_in via im2col (K = 36 -> 64)
     View x(a.alloc_h(M * top), top, top);
     {
@@ -192,27 +205,33 @@ int VAE::run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w) {
         if (go && !c.err) c.err = launch_pointwise_nchw(z, pq_w, pq_b, pq, B, lc, lc, (long)h * w, s);
         if (go && !c.err) c.err = launch_im2col_nchw3x3(pq, col, B, lc, h, w, (int)d_conv_in.K, s);
         ConvW pw = d_conv_in; pw.ks = 1;
-        op_conv(c, pw, View(col, d_conv_in.K, (int)d_conv_in.K), B, h, w, x);
+        ConvFuse f;
+        gn_fuse(f, (long)h * w, top);
+        op_conv(c, pw, View(col, d_conv_in.K, (int)d_conv_in.K), B, h, w, x, 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
+        xs = f.gn_out;
         a.release(mk);
     }
     // ping-pong activation buffers sized for the largest level, allocated once
     // (every resnet's temporaries are stack-released inside run_resnet)
     View y(a.alloc_h(M * top), top, top);
-    run_resnet(c, d_mid0, x, B, h, w, y, G, kVaeEps, nullptr, 0);
-    run_attn(c, d_attn, y, B, h, w, x);
-    run_resnet(c, d_mid1, x, B, h, w, y, G, kVaeEps, nullptr, 0);
+    run_resnet(c, d_mid0, x, B, h, w, y, G, kVaeEps, nullptr, 0, xs, &xs);
+    run_attn(c, d_attn, y, B, h, w, x, xs, &xs);
+    run_resnet(c, d_mid1, x, B, h, w, y, G, kVaeEps, nullptr, 0, xs, &xs);
     View cur = y;
     for (int i = 0; i < nb; ++i) {
         for (int j = 0; j < cfg.layers_per_block + 1; ++j) {
             const Resnet& r = d_up[i][j];
             View nxt(a.alloc_h(M * r.cout), r.cout, r.cout);
-            run_resnet(c, r, cur, B, h, w, nxt, G, kVaeEps, nullptr, 0);
+            run_resnet(c, r, cur, B, h, w, nxt, G, kVaeEps, nullptr, 0, xs, &xs);
             cur = nxt;
         }
         if (i != nb - 1) {
             const int C = d_us[i].cout;
             View nxt(a.alloc_h(M * 4 * C), C, C);
-            op_conv(c, d_us[i], cur, B, h, w, nxt, 1, 1);
+            ConvFuse f;
+            gn_fuse(f, (long)h * w * 4, C);
+            op_conv(c, d_us[i], cur, B, h, w, nxt, 1, 1, nullptr, 0, nullptr, 0, -1, 0, &f);
+            xs = f.gn_out;
             h *= 2; w *= 2; M *= 4;
             cur = nxt;
         }
@@ -220,7 +239,7 @@ int VAE::run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w) {
     {
         const int C = boc[0];
         View hn(a.alloc_h(M * C), C, C);
-        op_groupnorm(c, d_norm_out, cur, hn, B, (long)h * w, G, kVaeEps, 1);
+        op_groupnorm(c, d_norm_out, cur, hn, B, (long)h * w, G, kVaeEps, 1, xs);
         View o(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
         op_conv(c, d_conv_out, hn, B, h, w, o);
         if (go && !c.err) c.err = launch_nhwc_to_nchw(o.p, o.ld, img, B, (long)h * w, cfg.out_channels, s);
@@ -238,36 +257,48 @@ int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, in
     const bool go = !c.dry;
     int h = H, w = W;
     long M = (long)B * h * w;
+    ctx_gnpool_init(c, B, (long)H * W, G);
+    GnStatBuf* xs = nullptr;
+    auto gn_fuse = [&](ConvFuse& f, long HW, int C) {
+        f.gn_out = gn_wants_stats(HW, C, G) ? ctx_gnbuf(c) : nullptr;
+        f.gn_groups = G;
+    };
     View cur(a.alloc_h(M * boc[0]), boc[0], boc[0]);
     {
         const size_t mk = a.mark();
         half_t* col = a.alloc_h(M * e_conv_in.K);
         if (go && !c.err) c.err = launch_im2col_nchw3x3(img, col, B, cfg.in_channels, h, w, (int)e_conv_in.K, s);
         ConvW pw = e_conv_in; pw.ks = 1;
-        op_conv(c, pw, View(col, e_conv_in.K, (int)e_conv_in.K), B, h, w, cur);
+        ConvFuse f;
+        gn_fuse(f, (long)h * w, boc[0]);
+        op_conv(c, pw, View(col, e_conv_in.K, (int)e_conv_in.K), B, h, w, cur, 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
+        xs = f.gn_out;
         a.release(mk);
     }
     for (int i = 0; i < nb; ++i) {
         for (int j = 0; j < cfg.layers_per_block; ++j) {
             const Resnet& r = e_down[i][j];
             View nxt(a.alloc_h(M * r.cout), r.cout, r.cout);
-            run_resnet(c, r, cur, B, h, w, nxt, G, kVaeEps, nullptr, 0);
+            run_resnet(c, r, cur, B, h, w, nxt, G, kVaeEps, nullptr, 0, xs, &xs);
             cur = nxt;
         }
         if (i != nb - 1) {
             const int C = e_ds[i].cout;
             View nxt(a.alloc_h(M / 4 * C), C, C);
-            op_conv(c, e_ds[i], cur, B, h, w, nxt, 2, 0, nullptr, 0, nullptr, 0, /*pad=*/0);
+            ConvFuse f;
+            gn_fuse(f, (long)(h / 2) * (w / 2), C);
+            op_conv(c, e_ds[i], cur, B, h, w, nxt, 2, 0, nullptr, 0, nullptr, 0, /*pad=*/0, 0, &f);
+            xs = f.gn_out;
             h /= 2; w /= 2; M /= 4;
             cur = nxt;
         }
     }
     const int top = boc[nb - 1];
     View t0(a.alloc_h(M * top), top, top), t1(a.alloc_h(M * top), top, top);
-    run_resnet(c, e_mid0, cur, B, h, w, t0, G, kVaeEps, nullptr, 0);
-    run_attn(c, e_attn, t0, B, h, w, t1);
-    run_resnet(c, e_mid1, t1, B, h, w, t0, G, kVaeEps, nullptr, 0);
-    op_groupnorm(c, e_norm_out, t0, t1, B, (long)h * w, G, kVaeEps, 1);
+    run_resnet(c, e_mid0, cur, B, h, w, t0, G, kVaeEps, nullptr, 0, xs, &xs);
+    run_attn(c, e_attn, t0, B, h, w, t1, xs, &xs);
+    run_resnet(c, e_mid1, t1, B, h, w, t0, G, kVaeEps, nullptr, 0, xs, &xs);
+    op_groupnorm(c, e_norm_out, t0, t1, B, (long)h * w, G, kVaeEps, 1, xs);
     View o(a.alloc_h(M * lc2), lc2, lc2);
     op_conv(c, e_conv_out, t1, B, h, w, o);
     half_t* o_nchw = a.alloc_h(M * lc2);

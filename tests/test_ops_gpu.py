@@ -133,6 +133,76 @@ def test_groupnorm(engine_lib, N, HW, C, silu, eps):
     assert rel_l2(y, ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("N,HW,C,offset", [(1, 262144, 128, 50.0),     # VAE 512 px level: 1 M elements per group
+                                           (2, 4096, 320, 50.0),      # UNet 64 x 64 level (two-pass form)
+                                           (2, 1024, 640, 50.0),      # single-kernel form
+                                           (1, 16384, 512, -30.0)])
+def test_groupnorm_large_mean_small_spread(engine_lib, N, HW, C, offset):
+    """x = offset + 0.1 * randn.  With single-pass E[x^2] - mean^2 in fp32 the variance (0.01)
+    drowns in the cancellation (mean^2 = 2500) and rstd goes wrong by orders of magnitude; the kernels
+    keep shifted sums / (mean, M2) summaries merged with Chan's formula.  fp32 F.group_norm is the checker.
+    The input's own fp16 grid (spacing 0.03 at 50) is part of x on both sides."""
+    g = torch.Generator().manual_seed(HW + C)
+    x = (offset + 0.1 * torch.randn(N, HW, C, generator=g)).half()
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1)
+    y = torch.empty(N, HW, C, dtype=torch.float16, device="cuda")
+    xd, gd, bd = h(x), gamma.cuda(), beta.cuda()
+    rc = engine_lib.sd_op_groupnorm(P(xd), P(gd), P(bd), P(y), N, HW, C, 32, 1e-6, 0, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 1.5e-3
+
+
+CONV_GN_CASES = [
+    # N, H, W, Cin, Cout, k, stride, up, residual, expect the epilogue path
+    (2, 64, 64, 320, 320, 3, 1, 0, True, 1),      # UNet level 0 resnet conv2 (+residual) -> next GroupNorm (halo kernel)
+    (2, 64, 64, 320, 320, 3, 1, 0, False, 1),     # conv1 -> norm2
+    (2, 64, 64, 64, 320, 1, 1, 0, False, 1),      # conv_in as the im2col GEMM (pointwise)
+    (1, 128, 128, 256, 256, 3, 1, 0, True, 1),    # VAE level, cpg = 8
+    (1, 64, 64, 128, 128, 3, 1, 1, False, 1),     # VAE upsample conv (2x nearest in the gather), cpg = 4
+    (1, 128, 128, 128, 512, 3, 2, 0, False, 1),   # stride 2 (encoder / UNet downsample), cpg = 16
+    (2, 32, 32, 640, 640, 3, 1, 0, True, 0),      # small map: the single-kernel GroupNorm needs no summaries
+    (1, 40, 40, 64, 320, 3, 1, 0, False, None),   # 1600 pixels per image: whichever path, same numbers
+]
+
+
+@pytest.mark.parametrize("case", CONV_GN_CASES)
+def test_conv_groupnorm_statistics_from_the_conv_epilogue(engine_lib, case):
+    """conv -> GroupNorm(+SiLU) with the GroupNorm summaries written by the convolution's epilogue
+    (IGemmParams::gnstat_out) against conv2d + group_norm in fp32; also checks which path ran."""
+    N, H, W, Cin, Cout, k, stride, up, with_res, expect = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half()
+    bias = torch.randn(Cout, generator=g) * 0.5 + 0.3
+    gamma = 1 + 0.2 * torch.randn(Cout, generator=g)
+    beta = 0.2 * torch.randn(Cout, generator=g)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    conv = F.conv2d(xin, w.float(), bias, stride=stride, padding=1 if k == 3 else 0)
+    res = torch.randn(conv.shape, generator=g).half() if with_res else None
+    conv = conv.half().float()
+    if res is not None:
+        conv = (conv + res.float()).half().float()
+    ref = F.silu(F.group_norm(conv, 32, gamma, beta, 1e-5))
+    OH, OW = conv.shape[2], conv.shape[3]
+    yc = torch.empty(N, OH, OW, Cout, dtype=torch.float16, device="cuda")
+    yg = torch.empty_like(yc)
+    fused = C.c_int(-1)
+    xd = h(x.permute(0, 2, 3, 1))
+    rd = h(res.permute(0, 2, 3, 1)) if res is not None else None
+    rc = engine_lib.sd_op_conv2d_groupnorm(P(xd), P(h(w)), P(bias.cuda()), None, P(rd), P(yc), P(gamma.cuda()),
+                                           P(beta.cuda()), P(yg), N, H, W, Cin, Cout, k, stride, up, 32, 1e-5, 1,
+                                           C.byref(fused), stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    if expect is not None:
+        assert fused.value == expect
+    assert rel_l2(yc.permute(0, 3, 1, 2), conv) < 2e-3
+    assert rel_l2(yg.permute(0, 3, 1, 2), ref) < 3e-3
+
+
 @pytest.mark.parametrize("rows,C", [(300, 320), (1000, 640), (77, 1280), (5, 64)])
 def test_layernorm(engine_lib, rows, C):
     g = torch.Generator().manual_seed(rows)
