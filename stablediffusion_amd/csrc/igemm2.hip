@@ -181,10 +181,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     const bool b_hi = (B_REM == 0) || wave < B_REM;               // wave-uniform
     const int b_cnt = b_hi ? B_PW : B_PW - 1;
     const int b_first = b_hi ? wave * B_PW : B_REM * B_PW + (wave - B_REM) * (B_PW - 1);
+    // GEGLU with a 128-column tile over two wave columns: the packed weight rows of a tile are
+    // [64 hidden | 64 gate] (WeightStore::pack_geglu); the LDS image is filled as
+    // [hidden 0-31 | gate 0-31 | hidden 32-63 | gate 32-63], so each wave's 64 columns hold 32 hidden units
+    // next to their own gates and hidden * gelu(gate) is formed straight from the accumulators: no LDS
+    // staging pass, no second barrier pair (that pass plus its reads was ~30 % of the GEGLU GEMM's time).
+    constexpr bool GEGLU_REG = BN == 128 && WAVES_N == 2;
+    const bool greg = GEGLU_REG && p.geglu;
+    auto gperm = [](int r) { return r < 32 || r >= 96 ? r : (r < 64 ? r + 32 : r - 32); };   // LDS row -> packed row
     unsigned b_off[B_PW];
 #pragma unroll
-    for (int j = 0; j < B_PW; ++j)
-        b_off[j] = (unsigned)((((long)(n0 + (b_first + j) * RPI + lrow)) * p.K + chunk * 8) * 2);
+    for (int j = 0; j < B_PW; ++j) {
+        const int r = (b_first + j) * RPI + lrow;
+        b_off[j] = (unsigned)((((long)(n0 + (greg ? gperm(r) : r))) * p.K + chunk * 8) * 2);
+    }
 
     // tap state of the NEXT slab to issue
     // K order = [Cin/64][KH][KW][64] (misc.hip pack_conv_kernel): taps innermost
@@ -336,6 +346,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     // ---- fused epilogue through LDS (same as igemm.hip).  Every global load of the epilogue is issued
     //      in a batch ahead of its first use: one load-and-wait per accumulator tile (bias, row add) and
     //      per output chunk (residual) serialises 20-30 L2 round trips per block otherwise. ----
+    if constexpr (GEGLU_REG) {
+        if (p.geglu) {
+            static_assert(!GEGLU_REG || TN == 4, "wave tile = 32 hidden + 32 gate columns");
+            if (p.ln_stat) __syncthreads();          // the prologue's row statistics, written by other waves
+            const int out_n0 = n0 >> 1;
+            f4 bh[2], bg[2], wh[2], wg[2];
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                const int ch = n0 + gperm(wn * 64 + jh * 16 + fq * 4), cg = n0 + gperm(wn * 64 + 32 + jh * 16 + fq * 4);
+                bh[jh] = *reinterpret_cast<const f4*>(p.bias + ch);
+                bg[jh] = *reinterpret_cast<const f4*>(p.bias + cg);
+                if (p.ln_stat) {
+                    wh[jh] = *reinterpret_cast<const f4*>(p.ln_wsum + ch);
+                    wg[jh] = *reinterpret_cast<const f4*>(p.ln_wsum + cg);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int pr = wm * WTM + i * 16 + fr;
+                const int m = m0 + pr;
+                float mean = 0.f, rstd = 1.f;
+                if (p.ln_stat) { mean = sStat[pr * 2]; rstd = sStat[pr * 2 + 1]; }
+#pragma unroll
+                for (int jh = 0; jh < 2; ++jh) {
+                    f4 hv = acc[i][jh], gv = acc[i][jh + 2];
+                    if (p.ln_stat) { hv = (hv - mean * wh[jh]) * rstd; gv = (gv - mean * wg[jh]) * rstd; }
+                    hv += bh[jh]; gv += bg[jh];
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (half_t)(hv[e] * gelu_erf_f(gv[e]));
+                    if (m < p.M) *reinterpret_cast<h4*>(p.y + (long)m * p.ldy + out_n0 + wn * 32 + jh * 16 + fq * 4) = o;
+                }
+            }
+            return;
+        }
+    }
+    // (Measured and dropped for the plain GEMMs: storing straight from the accumulators as 8-byte pieces, as
+    // the GEGLU path above does, instead of staging through LDS -- within noise on q|k|v / to_q shapes.)
     __syncthreads();     // every wave is done with the ring before it is overlaid
     f4 bias4[TN], wsum4[TN];
 #pragma unroll
@@ -383,24 +431,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     }
     __syncthreads();
 
-    if (p.geglu) {
-        constexpr int OCH = BN / 16;
-        const int out_n0 = n0 >> 1;
-        for (int idx = tid; idx < BM * OCH; idx += NT) {
-            const int r = idx / OCH, oc = (idx - r * OCH) * 8;
-            const int m = m0 + r;
-            const int hcol = (oc >> 6) * 128 + (oc & 63);
-            if (m < p.M && n0 + hcol < p.Cout) {
-                const h8 hv = *reinterpret_cast<const h8*>(sC + r * LDC + hcol);
-                const h8 gv = *reinterpret_cast<const h8*>(sC + r * LDC + hcol + 64);
-                h8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)hv[e] * gelu_erf_f((float)gv[e]));
-                *reinterpret_cast<h8*>(p.y + (long)m * p.ldy + out_n0 + oc) = o;
-            }
-        }
-        return;
-    }
     // Output pass: thread t owns the 16-byte column chunk t % CH of the rows t / CH + k * RPP (the last
     // NT % CH threads sit out): a fixed column per thread, so the per-group sums a following GroupNorm
     // needs accumulate in registers across the thread's rows.
@@ -540,6 +570,12 @@ __host__ __device__ inline int halo_patch_width(int H, int W) {
     return 0;
 }
 
+// No GroupNorm summaries from this kernel's epilogue (igemm2_kernel has them): it sits on the 256-VGPR
+// ceiling, and with the summary code in -- in any form tried: accumulated in the store loop, in a second
+// loop, behind a noinline call -- the register allocator moves a dozen loop-invariant address registers to
+// scratch and reloads them inside the main loop: 58.8 -> 72.7 us on the 64x64 320->320 conv, more than the
+// 19 us statistics pass it would save.  (Its 8 spilled dwords stay outside the loop; check
+// `scratch_` against the v_mfma range in the ISA after any change here.)
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float* partial, int slabs_per_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr unsigned kOOB = 0x80000000u;
@@ -770,10 +806,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
                                      : h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
-    const int cpg = p.gnstat_out ? p.Cout / p.gn_groups : 8;
-    const int g_first = n / cpg;
-    const int gsplit = (g_first + 1) * cpg - n;
-    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int r = rr + it * RPP;
@@ -784,18 +816,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[it][e]);
             }
             *reinterpret_cast<h8*>(p.y + (long)row_of(r) * p.ldy + n) = v;
-            if (p.gnstat_out) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    if (e < gsplit) { gs0 += f; gq0 += f * f; } else { gs1 += f; gq1 += f * f; }
-                }
-            }
         }
     }
-    if (p.gnstat_out)
-        gn_tile_stats<BM, BN, NT>(reinterpret_cast<float*>(smem + BM * LDC * 2), tid, gs0, gq0, gs1, gq1, n0, p.Cout, cpg,
-                                  p.gn_groups, p.gnstat_out + ((long)img * patches + pidx) * p.gn_groups * 2);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -849,6 +871,7 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     IGemmParams q = p;
     q.mfast = weights_outweigh_activations(p);
     q.rowstat_parts = cdiv(p.Cout, BN);
+    if (p.geglu && !(BN == 128 && WN == 2)) { set_error("igemm2: GEGLU needs a 128-column tile over two wave columns"); return 1; }
     if (eff_splits > 1 && (p.rowstat_out || p.ln_stat)) { set_error("igemm2: row statistics / LayerNorm fold need splits == 1"); return 1; }
     hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
                        q, eff_splits > 1 ? partial : nullptr, per);
@@ -953,6 +976,7 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
     igemm2_pick(p, &v, &sp);
     if (sp > 1) return false;
     if (v == 10 && !halo_supported(p)) v = 7;
+    if (v == 10) return false;                          // see conv3x3_halo_kernel
     int bm, bn;
     tile_dims(v, &bm, &bn);
     const int OHW = p.OH * p.OW;

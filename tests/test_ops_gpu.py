@@ -159,8 +159,8 @@ CONV_GN_CASES = [
     # N, H, W, Cin, Cout, k, stride, up, residual, expect the epilogue path
     # `expect`: 1 = the tuned table gives this shape a tile whose epilogue can leave the summaries (C2's own
     # shapes), None = whichever tile / split-K the heuristic picks, the numbers must not depend on it
-    (8, 64, 64, 320, 320, 3, 1, 0, True, 1),      # UNet level 0 resnet conv2 (+residual) -> next GroupNorm (halo kernel)
-    (8, 64, 64, 320, 320, 3, 1, 0, False, 1),     # conv1 -> norm2
+    (8, 64, 64, 320, 320, 3, 1, 0, True, 0),      # UNet level 0 resnet conv2: the halo kernel leaves none (register ceiling)
+    (8, 64, 64, 320, 320, 1, 1, 0, True, 1),      # Transformer2D proj_out (+residual) -> conv_norm_out / next block
     (2, 64, 64, 320, 320, 3, 1, 0, True, None),
     (2, 64, 64, 64, 320, 1, 1, 0, False, None),   # conv_in as the im2col GEMM (pointwise)
     (4, 128, 128, 256, 256, 3, 1, 0, True, None), # VAE level, cpg = 8
