@@ -83,42 +83,111 @@ def live_roofline(lib, unet, vae, B, lat_hw, ehs, device, added=None):
     return unet_rows, vae_rows
 
 
-def pmc_traffic_for(kernel_label: str):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_hbm_traffic_per_launch.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE;
-    PMC passes cannot run inside the timed bench).  Kernel labels are the rocprofv3 names."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_per_launch.json")
-    if not os.path.exists(path):
+def _profile_file(stem: str):
+    """Newest committed profile of that kind: profiles/r02_<stem>, else round 1's."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_{stem}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def pmc_traffic_for(function: str):
+    """HBM bytes per launch of the roofline kernel function from the committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_hbm_traffic_per_launch.json: FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE, separate
+    passes; PMC passes cannot run inside the timed bench), launch-weighted over its template instantiations."""
+    path = _profile_file("pmc_hbm_traffic_per_launch.json")
+    if not path:
         return None
     data = json.load(open(path))
-    e = data.get(kernel_label.replace("+splitk", ""))
-    if not e:
+    rows = [e for k, e in data.items() if isinstance(e, dict) and k.split("<")[0] == function]
+    n = sum(e["launches"] for e in rows)
+    if not n:
         return None
-    return {"hbm_MB_per_launch": round(e["fetch_MB_per_launch"] + e["write_MB_per_launch"], 2),
-            "source": "profiles/r01_pmc_hbm_traffic_per_launch.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                      "separate passes, FETCH_SIZE doubled for gfx950; average over all launches of the kernel "
-                      "in that run)"}
+    mb = sum((e["fetch_MB_per_launch"] + e["write_MB_per_launch"]) * e["launches"] for e in rows) / n
+    return {"hbm_MB_per_launch": round(mb, 2),
+            "source": f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE "
+                      f"doubled for gfx950; launch-weighted average over every instantiation of {function} in that run)"}
 
 
-def rocprof_avg_us_for(kernel_label: str):
-    """Average duration of the roofline kernel in the committed rocprofv3 --kernel-trace --stats summary of
-    this same command (profiles/r01_bench_kernel_stats.csv).  The live HIP-event bracket reads ~10 % longer
-    than the trace: an event between two launches keeps the next kernel's ramp from overlapping the
-    previous kernel's tail, which is how the kernels run in the timed loop."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_kernel_stats.csv")
-    if not os.path.exists(path):
+def rocprof_avg_us_for(function: str):
+    """Average launch duration of the kernel function in the committed rocprofv3 --kernel-trace --stats summary
+    of this same command (profiles/rNN_bench_kernel_stats.csv), over all its instantiations.  The live
+    HIP-event bracket reads ~10 % longer than the trace: an event between two launches keeps the next kernel's
+    ramp from overlapping the previous kernel's tail, which is how the kernels run in the timed loop."""
+    path = _profile_file("bench_kernel_stats.csv")
+    if not path:
         return None
     import csv
-    want = kernel_label.replace(" ", "")
-    m = re.match(r"(\w+)<(\d+)>$", want)          # e.g. attn_kernel<40> -> mangled attn_kernelILi40E...
-    mangled = f"{m.group(1)}ILi{m.group(2)}E" if m else None
     tot = n = 0.0
     for row in csv.DictReader(open(path)):
-        name = row["Name"].replace(" ", "")
-        if want in name or (mangled and mangled in name):
+        if function in row["Name"]:
             tot += float(row["TotalDurationNs"])
             n += float(row["Calls"])
     return round(tot / n / 1e3, 2) if n else None
+
+
+KERNEL_FAMILIES = (("conv/GEMM", ("igemm2_kernel", "conv3x3_halo_kernel", "igemm_kernel")), ("attention", ("attn_kernel",)),
+                   ("norms", ("groupnorm", "layernorm", "row_stats")))
+
+
+def kernel_function(row_name: str) -> str:
+    """`igemm2_kernel<256,160,...>` -> `igemm2_kernel`: template instantiations are one kernel function."""
+    return row_name.split("<")[0].split("(")[0]
+
+
+def roofline_report(urows, vrows):
+    """`roofline` = the kernel FUNCTION with the largest summed time in one UNet forward (all its template
+    instantiations together), next to the per-family aggregates, the whole-forward figure and
+    the single best instantiation.  achieved = sum of algorithmic FLOPs of its launches / sum of their
+    HIP-event times on the launch stream; peak = 2.5 PFLOP/s dense fp16 (MI355X_MICROARCH.md:43)."""
+    def agg(rows, pred):
+        sel = [r for r in rows if pred(r[0])]
+        return (sum(r[1] for r in sel), sum(r[2] for r in sel), sum(r[3] for r in sel), sum(r[4] for r in sel))
+
+    out = {}
+    funcs = sorted({kernel_function(r[0]) for r in urows}, key=lambda f: -agg(urows, lambda n: kernel_function(n) == f)[2])
+    top = funcs[0]
+    flops, nbytes, ms, launches = agg(urows, lambda n: kernel_function(n) == top)
+    fam_rows = []
+    for fam, names in KERNEL_FAMILIES:
+        f, b, m, l = agg(urows, lambda n: kernel_function(n) in names or any(n.startswith(x) for x in names))
+        if l:
+            fam_rows.append({"family": fam, "ms": round(m, 3), "launches": l,
+                             "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 else None,
+                             "mfma_frac": round(f / (m / 1e3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if f > 0 else None,
+                             "gbs": round(b / (m / 1e3) / 1e9, 1)})
+    tf, tb, tm, tl = agg(urows, lambda n: True)
+    best = max((r for r in urows if r[1] > 0 and r[3] > 0), key=lambda r: r[1] / r[3])
+    if flops > 0:
+        ach = flops / (ms / 1e3) / 1e12
+        out["roofline"] = {"kernel": top, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_for(top),
+                           "launches_per_unet_forward": launches,
+                           "algorithmic_MB_per_launch": round(nbytes / launches / 1e6, 2),
+                           "avg_launch_us": round(ms / launches * 1e3, 2),
+                           "rocprofv3_avg_launch_us": rocprof_avg_us_for(top),
+                           "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
+                           "scope": "all template instantiations of the function, one UNet forward (CFG batch)"}
+    else:
+        ach = nbytes / (ms / 1e3) / 1e9
+        out["roofline"] = {"kernel": top, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches_per_unet_forward": launches,
+                           "avg_launch_us": round(ms / launches * 1e3, 2)}
+    out["roofline"]["families"] = fam_rows
+    out["roofline"]["whole_forward"] = {"ms_sum_of_launches": round(tm, 3), "launches": tl,
+                                        "mfma_frac": round(tf / (tm / 1e3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    out["roofline"]["best_instantiation"] = {"kernel": best[0], "launches": best[4],
+                                             "tflops": round(best[1] / (best[3] / 1e3) / 1e12, 1),
+                                             "mfma_frac": round(best[1] / (best[3] / 1e3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    out["unet_forward_profiled_sum_ms"] = round(tm, 3)
+    fmt = lambda rows: [{"kernel": k, "ms": round(m, 3), "launches": l,
+                         "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,
+                         "gbs": round(b / (m / 1e3) / 1e9, 1) if m > 0 else None}
+                        for k, f, b, m, l in sorted(rows, key=lambda r: -r[3])]
+    out["kernels_unet_forward"] = fmt(urows)
+    out["kernels_vae_decode"] = fmt(vrows)
+    return out
 
 
 def usable_cores() -> int:
@@ -136,36 +205,41 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(ucfg, vcfg, usd, vsd, steps, lat_hw, ehs_len):
-    """fp32 CPU oracle ("port") on a bounded sample of the same workload: one UNet forward at CFG
-    batch 2 (= one latent) and one VAE decode of one latent, both at a quarter of the latent area,
-    scaled to the full resolution by the algorithmic-FLOP ratio of SURVEY.md §8(d)."""
-    from oracle import unet_ref, vae_ref
+    """fp32 CPU oracle ("port": the build's restatement of the reference's diffusers CPU float32 path) on a
+    bounded sample, about 10-15 s of CPU work on the box's cores:
+      * BASELINE.json config C1 run whole, as SURVEY.md section 8(d) specifies: SD1.5 256 px (32x32 latents),
+        10-step DDIM, batch 1, CFG on, decode included -- reported under `c1_measured`;
+      * for `value` (same unit and workload as `metric`): ONE UNet forward at CFG batch 2 and ONE VAE decode at
+        the benchmark's own latent size, measured directly (no FLOP-ratio extrapolation), times the step count."""
+    from oracle import pipeline_ref, unet_ref, vae_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
-    hw = lat_hw // 2
-    ut = UNET_TFLOP_PER_SAMPLE["sd15"]
-    u_scale = ut.get(lat_hw, 4 * ut.get(hw, 1)) / ut.get(hw, 1)
-    v_scale = VAE_TFLOP_PER_IMAGE.get(lat_hw, 4 * VAE_TFLOP_PER_IMAGE.get(hw, 1)) / VAE_TFLOP_PER_IMAGE.get(hw, 1)
     g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         uw = {k: v.float() for k, v in usd.items()}
-        x = torch.randn(2, 4, hw, hw, generator=g)
-        e = torch.randn(2, ehs_len, ucfg.cross_attention_dim, generator=g)
-        t0 = time.time()
-        unet_ref.unet_forward(ucfg, uw, x, torch.tensor(501.0), e)
-        t_unet = time.time() - t0
-        del uw
         vw = {k: v.float() for k, v in vsd.items()}
-        z = torch.randn(1, 4, hw, hw, generator=g)
+        lat = torch.randn(1, 4, 32, 32, generator=g)
+        emb2 = torch.randn(2, ehs_len, ucfg.cross_attention_dim, generator=g)
+        t0 = time.time()
+        img, _ = pipeline_ref.txt2img_ref(ucfg, uw, vcfg, vw, lat, emb2, steps=10, guidance_scale=5.0)
+        t_c1 = time.time() - t0
+        assert img.shape == (1, 3, 256, 256) and bool(torch.isfinite(img).all())
+        x = torch.randn(2, 4, lat_hw, lat_hw, generator=g)
+        t0 = time.time()
+        unet_ref.unet_forward(ucfg, uw, x, torch.tensor(501.0), emb2)
+        t_unet = time.time() - t0
+        z = torch.randn(1, 4, lat_hw, lat_hw, generator=g)
         t0 = time.time()
         vae_ref.vae_decode(vcfg, vw, z)
         t_vae = time.time() - t0
-    per_latent = steps * t_unet * u_scale + t_vae * v_scale
+    per_latent = steps * t_unet + t_vae
     return {
         "value": 1.0 / per_latent, "unit": "latents/s", "cores": cores, "kind": "port",
         "sample": (f"oracle (fp32 torch CPU restatement of the reference's diffusers path), {cores} threads: "
-                   f"1 UNet forward at CFG batch 2 on {hw}x{hw} latents = {t_unet:.2f}s, x{u_scale:.2f} (FLOP ratio to "
-                   f"{lat_hw}x{lat_hw}) x {steps} steps; 1 VAE decode of a {hw}x{hw} latent = {t_vae:.2f}s, x{v_scale:.2f}"),
+                   f"1 UNet forward at CFG batch 2 on {lat_hw}x{lat_hw} latents = {t_unet:.2f}s (x {steps} steps) + "
+                   f"1 VAE decode of a {lat_hw}x{lat_hw} latent = {t_vae:.2f}s, both measured at the benchmark's size"),
+        "c1_measured": {"workload": "BASELINE.json C1: SD1.5 256x256, 10-step DDIM, batch 1, CFG on, decode included",
+                        "seconds": round(t_c1, 2), "latents_per_s": round(1.0 / t_c1, 4)},
     }
 
 
@@ -390,36 +464,7 @@ def main():
             result["unet_forward_mfma_frac"] = round(2 * B * u_tf / (unet_ms / 1e3) / MFMA_PEAK_TFLOPS, 4)
         if not args.no_roofline:
             urows, vrows = live_roofline(lib, unet, vae, B, lat_hw, e8, device, added)
-            urows.sort(key=lambda r: -r[3])
-            name, flops, nbytes, ms, launches = urows[0]
-            if flops > 0:
-                ach = flops / (ms / 1e3) / 1e12
-                result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2),
-                                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_for(name),
-                                      "launches_per_unet_forward": launches,
-                                      "algorithmic_MB_per_launch": round(nbytes / launches / 1e6, 2),
-                                      "avg_launch_us": round(ms / launches * 1e3, 2),
-                                      "rocprofv3_avg_launch_us": rocprof_avg_us_for(name),
-                                      "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3)}
-            else:
-                ach = nbytes / (ms / 1e3) / 1e9
-                result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1),
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                      "traffic": None, "launches_per_unet_forward": launches,
-                                      "avg_launch_us": round(ms / launches * 1e3, 2)}
-            result["unet_forward_profiled_sum_ms"] = round(sum(r[3] for r in urows), 3)
-            result["kernels_unet_forward"] = [
-                {"kernel": k, "ms": round(m, 3), "launches": l,
-                 "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,
-                 "gbs": round(b / (m / 1e3) / 1e9, 1) if m > 0 else None}
-                for k, f, b, m, l in urows]
-            vrows.sort(key=lambda r: -r[3])
-            result["kernels_vae_decode"] = [
-                {"kernel": k, "ms": round(m, 3), "launches": l,
-                 "tflops": round(f / (m / 1e3) / 1e12, 1) if f > 0 and m > 0 else None,
-                 "gbs": round(b / (m / 1e3) / 1e9, 1) if m > 0 else None}
-                for k, f, b, m, l in vrows]
+            result.update(roofline_report(urows, vrows))
         if n_gpus == 1 and not args.no_cpu_baseline and args.preset == "sd15":
             del unet, vae, model
             torch.cuda.empty_cache()

@@ -128,6 +128,12 @@ int sd_unet_forward(sd_unet* u, const void* sample, const float* timesteps, cons
  * through engine-owned buffers, fenced against `stream` with events).  Host cost per forward drops
  * from ~480 kernel launches to one hipGraphLaunch; results are bitwise those of the eager path. */
 int sd_unet_use_graph(sd_unet* u, int enable);
+/* Text K/V reuse across the forwards of ONE denoise loop (sd_unified_pipeline.py:465-507 passes the same
+ * prompt_embeds to every step): enable = 1 makes the next forward compute the stacked attn2.to_k / to_v
+ * projections of encoder_hidden_states and later forwards with the same (pointer, batch, length) reuse
+ * them.  Every call of this function -- with 1 or 0 -- invalidates what is cached: call it (again) whenever
+ * the CONTENTS behind the pointer may have changed, i.e. at the start of each pipeline call.  Off by default. */
+int sd_unet_text_kv_cache(sd_unet* u, int enable);
 /* Bytes of device memory held (packed weights, workspace). */
 int sd_unet_memory(const sd_unet* u, int64_t* weight_bytes, int64_t* workspace_bytes);
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "sd_unet_finalize": (_I, [_P]),
     "sd_unet_forward": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "sd_unet_use_graph": (_I, [_P, _I]),
+    "sd_unet_text_kv_cache": (_I, [_P, _I]),
     "sd_unet_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "sd_vae_create": (_I, [C.POINTER(SdVAEConfig), C.POINTER(_P)]),
     "sd_vae_destroy": (_I, [_P]),

@@ -83,6 +83,12 @@ int sd_unet_use_graph(sd_unet* u, int enable) {
     u->impl.graph_enabled = enable != 0;
     return SD_OK;
 }
+int sd_unet_text_kv_cache(sd_unet* u, int enable) {
+    if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
+    u->impl.kv_cache_on = enable != 0;
+    u->impl.kv_valid = false;           // every call invalidates: the next forward recomputes
+    return SD_OK;
+}
 int sd_unet_memory(const sd_unet* u, int64_t* weight_bytes, int64_t* workspace_bytes) {
     if (!u) { set_error("null handle"); return SD_ERR_INVALID; }
     if (weight_bytes) *weight_bytes = u->impl.ws.packed_bytes();

@@ -68,6 +68,16 @@ struct UNet {
                       const float* add_time_ids, half_t* out, int B, int H, int W, hipStream_t stream);
     ~UNet();
 
+    // ---- text K/V kept across the forwards of one denoise loop (sd_unet_text_kv_cache) ----
+    // encoder_hidden_states is constant over the loop, so the stacked to_k / to_v projection of every
+    // cross-attention block is computed by the first forward and reused by the other 49.
+    // Valid for one (pointer, batch, length); the caller invalidates when the CONTENTS behind the pointer change.
+    bool kv_cache_on = false, kv_valid = false;
+    half_t* kv_cache = nullptr;
+    size_t kv_cap = 0;
+    const half_t* kv_src = nullptr;
+    int kv_B = 0, kv_L = 0;
+
     ConvW conv_in, conv_out, te1, te2, ae1, ae2, temb_stack;
     ConvW kv_all;                       // every attn2.to_k / to_v of the model, row-concatenated
     std::vector<std::string> kv_keys;   // (finalize only)

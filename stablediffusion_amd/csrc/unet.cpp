@@ -404,8 +404,12 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     if (go && !c.err) c.err = launch_small_linear(emb, temb, temb_stack.w, temb_stack.bias, tproj, temb_total, B, temb, temb_total, 0, 0, s);
 
     // ---- text K/V of every cross-attention block in one GEMM: [B*L, ctx] x [ctx, sum 2C] ----
-    View text_kv(a.alloc_h((long)B * L * kv_total), kv_total, kv_total);
-    op_conv(c, kv_all, View(const_cast<half_t*>(ehs), cfg.cross_attention_dim, cfg.cross_attention_dim), B, L, 1, text_kv);
+    const bool kv_cached = kv_cache_on && !graph_enabled && kv_cache != nullptr;
+    View text_kv(kv_cached ? kv_cache : a.alloc_h((long)B * L * kv_total), kv_total, kv_total);
+    if (!(kv_cached && kv_valid && kv_src == ehs && kv_B == B && kv_L == L)) {
+        op_conv(c, kv_all, View(const_cast<half_t*>(ehs), cfg.cross_attention_dim, cfg.cross_attention_dim), B, L, 1, text_kv);
+        if (kv_cached && go && !c.err) { kv_valid = true; kv_src = ehs; kv_B = B; kv_L = L; }
+    }
 
     // ---- skip / concat buffer plan ----
     // Skip tensors are produced in down-path order and consumed by the up path in reverse; each
@@ -568,6 +572,7 @@ UNet::~UNet() {
     if (ev_out) (void)hipEventDestroy(ev_out);
     if (gstream) (void)hipStreamDestroy(gstream);
     if (io_slab) (void)hipFree(io_slab);
+    if (kv_cache) (void)hipFree(kv_cache);
 }
 
 // Graph path: stage I/O through engine-owned buffers, capture the forward once per shape on an
@@ -650,7 +655,17 @@ int UNet::forward(const half_t* sample, const float* timesteps, const half_t* eh
     if (B <= 0 || H % div != 0 || W % div != 0) { set_error("unet: H and W must be divisible by 2^(blocks-1)"); return 1; }
     if (graph_enabled && !prof_enabled())
         return forward_graph(sample, timesteps, ehs, L, add_text, add_time_ids, out, B, H, W, stream);
-    const long key = ((long)B << 40) ^ ((long)H << 20) ^ (long)W ^ ((long)L << 52);
+    if (kv_cache_on) {          // persistent buffer for the text K/V (outside the per-forward arena)
+        const size_t need = (size_t)B * L * kv_total * sizeof(half_t);
+        if (need > kv_cap) {
+            SD_HIP_CHECK(hipDeviceSynchronize());
+            if (kv_cache) (void)hipFree(kv_cache);
+            kv_cache = nullptr; kv_cap = 0; kv_valid = false;
+            SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&kv_cache), need));
+            kv_cap = need;
+        }
+    }
+    const long key = ((long)B << 40) ^ ((long)H << 20) ^ (long)W ^ ((long)L << 52) ^ (kv_cache_on ? (1L << 62) : 0);
     if (key != planned_key) {
         Ctx dry{&arena, stream, true};
         arena.begin(true);

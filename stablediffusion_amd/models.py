@@ -129,6 +129,13 @@ class HipUNet2DConditionModel:
         _lib.check(self._lib.sd_unet_use_graph(self._h, int(bool(enable))), "sd_unet_use_graph")
         return self
 
+    def text_kv_cache(self, enable: bool = True):
+        """Reuse the cross-attention K/V projections of `encoder_hidden_states` across the forwards of one
+        denoise loop (same tensor every step).  Each call invalidates the cache; the pipeline calls it with
+        True before its loop and with False after it."""
+        _lib.check(self._lib.sd_unet_text_kv_cache(self._h, int(bool(enable))), "sd_unet_text_kv_cache")
+        return self
+
     # -- reference surface ---------------------------------------------------------------------
     def to(self, device=None, dtype=None):
         if device is not None and torch.device(device).type != "cuda":
@@ -150,8 +157,12 @@ class HipUNet2DConditionModel:
             raise ValueError(f"encoder_hidden_states batch {ehs.shape[0]} != sample batch {B}")
         if ehs.shape[2] != self.cfg.cross_attention_dim:
             raise ValueError("encoder_hidden_states width != cross_attention_dim")
-        t = torch.as_tensor(timestep, device=dev).to(torch.float32).reshape(-1)
-        t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
+        if isinstance(timestep, (int, float)):
+            # a fill kernel, not a pageable host-to-device copy (which synchronises) on every step
+            t = torch.full((B,), float(timestep), device=dev, dtype=torch.float32)
+        else:
+            t = torch.as_tensor(timestep, device=dev).to(torch.float32).reshape(-1)
+            t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
         add_text = add_ids = None
         pt = pi = None
         if self.cfg.addition_embed_type == "text_time":

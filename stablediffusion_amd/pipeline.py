@@ -273,6 +273,11 @@ class StableDiffusionUnifiedPipeline:
         # the UNet forward of every step.  One copy of the schedule to the host before the loop
         # removes those 50 bubbles; the values are the same.
         timesteps_host = [float(v) for v in timesteps.tolist()]
+        # prompt_embeds is the same tensor on every step: the engine keeps its cross-attention K/V
+        # projections for the duration of this loop (switched off again right after it)
+        kv_cache = getattr(model.base, "text_kv_cache", None)
+        if kv_cache is not None:
+            kv_cache(True)
         fused_step = self._fused_step_available(model, latents, num_channels_unet)
         fused_hist = None
         blend = None
@@ -280,35 +285,40 @@ class StableDiffusionUnifiedPipeline:
             f16 = lambda x: x.to(device=latents.device, dtype=torch.float16).contiguous()
             m1 = mask.chunk(2)[0] if self.do_classifier_free_guidance else mask
             blend = (f16(image_latents), f16(noise), f16(m1.expand(latents.shape[0], 1, *latents.shape[2:])))
-        for i, t in enumerate(timesteps_host):
-            if fused_step:
-                latents, fused_hist = self._fused_cfg_iteration(model, latents, fused_hist, t, prompt_embeds,
-                                                                cross_attention_kwargs, added_cond_kwargs,
-                                                                guidance_scale)
-                if blend is not None:
-                    last = i == len(timesteps_host) - 1
-                    a, b = (1.0, 0.0) if last else model.scheduler.add_noise_coefficients(timesteps_host[i + 1])
-                    self._device_inpaint_blend(model, latents, blend, a, b, with_noise=not last)
-                continue
-            latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
-            latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
-            if self.is_inpaint and num_channels_unet == 9:
-                latent_model_input = torch.cat([latent_model_input, mask.to(latent_model_input.dtype),
-                                                masked_image_latents_2b.to(latent_model_input.dtype)], dim=1)
-            noise_pred = model.base(latent_model_input, t, prompt_embeds,
-                                    cross_attention_kwargs=cross_attention_kwargs,
-                                    added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
-            if self.do_classifier_free_guidance:
-                noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
-                noise_pred = guidance_scale * (noise_pred_text - noise_pred_uncond) + noise_pred_uncond
-            latents = model.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
-            if self.is_inpaint and num_channels_unet == 4:          # :492-506
-                init_latents_proper = image_latents
-                init_mask = mask.chunk(2)[0] if self.do_classifier_free_guidance else mask
-                if i < len(timesteps_host) - 1:
-                    init_latents_proper = model.scheduler.add_noise(init_latents_proper, noise,
-                                                                    torch.as_tensor([timesteps_host[i + 1]]))
-                latents = ((1 - init_mask) * init_latents_proper.float() + init_mask * latents.float()).to(latents.dtype)
+        try:
+            for i, t in enumerate(timesteps_host):
+                if fused_step:
+                    latents, fused_hist = self._fused_cfg_iteration(model, latents, fused_hist, t, prompt_embeds,
+                                                                    cross_attention_kwargs, added_cond_kwargs,
+                                                                    guidance_scale)
+                    if blend is not None:
+                        last = i == len(timesteps_host) - 1
+                        a, b = (1.0, 0.0) if last else model.scheduler.add_noise_coefficients(timesteps_host[i + 1])
+                        self._device_inpaint_blend(model, latents, blend, a, b, with_noise=not last)
+                    continue
+                latent_model_input = torch.cat([latents] * 2) if self.do_classifier_free_guidance else latents
+                latent_model_input = model.scheduler.scale_model_input(latent_model_input, t)
+                if self.is_inpaint and num_channels_unet == 9:
+                    latent_model_input = torch.cat([latent_model_input, mask.to(latent_model_input.dtype),
+                                                    masked_image_latents_2b.to(latent_model_input.dtype)], dim=1)
+                noise_pred = model.base(latent_model_input, t, prompt_embeds,
+                                        cross_attention_kwargs=cross_attention_kwargs,
+                                        added_cond_kwargs=added_cond_kwargs, return_dict=False)[0]
+                if self.do_classifier_free_guidance:
+                    noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+                    noise_pred = guidance_scale * (noise_pred_text - noise_pred_uncond) + noise_pred_uncond
+                latents = model.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+                if self.is_inpaint and num_channels_unet == 4:          # :492-506
+                    init_latents_proper = image_latents
+                    init_mask = mask.chunk(2)[0] if self.do_classifier_free_guidance else mask
+                    if i < len(timesteps_host) - 1:
+                        init_latents_proper = model.scheduler.add_noise(init_latents_proper, noise,
+                                                                        torch.as_tensor([timesteps_host[i + 1]]))
+                    latents = ((1 - init_mask) * init_latents_proper.float() + init_mask * latents.float()).to(latents.dtype)
+
+        finally:
+            if kv_cache is not None:
+                kv_cache(False)
 
         # ---- decode (:511-529) ----
         if self.output_type == "pt":

@@ -56,6 +56,29 @@ def test_unet_per_sample_timesteps_and_determinism(engine_lib, tiny_unet):
     assert torch.equal(a, b)                     # no atomics anywhere: bitwise reproducible
 
 
+def test_text_kv_cache_reuses_and_invalidates(engine_lib, tiny_unet):
+    """sd_unet_text_kv_cache: inside a denoise loop the cross-attention K/V of the (constant) prompt embeddings
+    are computed once; the result is bitwise the uncached one, a float timestep takes the same path as a
+    tensor, and re-arming the cache picks up new contents behind the same pointer."""
+    cfg, sd, net = tiny_unet
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 4, 16, 16, generator=g).half().cuda()
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).half().cuda()
+    base = net(x, torch.tensor(501.0), ehs)[0]
+    try:
+        net.text_kv_cache(True)
+        a = net(x, 501.0, ehs)[0]                 # fills the cache
+        b = net(x, 501.0, ehs)[0]                 # reuses it
+        assert torch.equal(a, base) and torch.equal(b, base)
+        ehs.mul_(0.5)                             # new contents, same pointer
+        net.text_kv_cache(True)                   # what the pipeline does at the start of every call
+        c = net(x, 501.0, ehs)[0]
+    finally:
+        net.text_kv_cache(False)
+    fresh = net(x, torch.tensor(501.0), ehs)[0]
+    assert torch.equal(c, fresh) and not torch.equal(c, base)
+
+
 def test_unet_batch_independence(engine_lib, tiny_unet):
     """Sharding property: a sample's result does not depend on its batch mates.
     Tile shape / split-K are picked per problem size, so a different batch size may change the fp32
