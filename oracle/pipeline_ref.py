@@ -15,9 +15,11 @@ import torch
 
 from .unet_ref import unet_forward
 from .vae_ref import vae_decode
-from .schedulers_ref import DDIMRef, DPMpp2MRef, EulerRef
+from .schedulers_ref import DDIMRef, DPMpp2MKarrasRef, DPMpp2MRef, EulerRef, PNDMRef, UniPCRef
 
-SCHEDULERS = {"DDIM": DDIMRef, "DPM++ 2M": DPMpp2MRef, "euler": EulerRef}
+# the deterministic schedulers of the registry (the stochastic ones take their noise explicitly: tests only)
+SCHEDULERS = {"DDIM": DDIMRef, "DPM++ 2M": DPMpp2MRef, "euler": EulerRef, "DPM++ 2M Karras": DPMpp2MKarrasRef,
+              "PNDM": PNDMRef, "uni_pc": UniPCRef}
 
 
 @torch.no_grad()

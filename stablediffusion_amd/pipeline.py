@@ -358,7 +358,8 @@ class StableDiffusionUnifiedPipeline:
         of `:492-506` follows as a third kernel (`sd_inpaint_blend`).  Only with CFG on the HIP engine;
         9-channel inpainting UNets and non-CFG calls take the generic path."""
         return (self.do_classifier_free_guidance and (not self.is_inpaint or num_channels_unet == 4)
-                and hasattr(model.scheduler, "fused_plan") and hasattr(model.scheduler, "add_noise_coefficients")
+                and hasattr(model.scheduler, "fused_plan") and getattr(model.scheduler, "supports_fused", True)
+                and hasattr(model.scheduler, "add_noise_coefficients")
                 and hasattr(model.base, "_lib") and latents.is_cuda and latents.dtype == torch.float16)
 
     def _fused_cfg_iteration(self, model, latents, hist, t, prompt_embeds, cross_attention_kwargs, added_cond_kwargs,

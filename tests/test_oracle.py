@@ -191,6 +191,51 @@ def test_unknown_timestep_is_rejected_by_sigma_schedulers():
         s.scale_model_input(torch.zeros(1), 123.0)
 
 
+@pytest.mark.parametrize("name,ref_cls,n", [("euler_a", schedulers_ref.EulerAncestralRef, 6),
+                                            ("DPM++ 2M Karras", schedulers_ref.DPMpp2MKarrasRef, 9),
+                                            ("DPM++ 2M SDE Karras", schedulers_ref.DPMpp2MSDERef, 7),
+                                            ("PNDM", schedulers_ref.PNDMRef, 8), ("uni_pc", schedulers_ref.UniPCRef, 7),
+                                            ("uni_pc", schedulers_ref.UniPCRef, 2)])
+def test_remaining_registry_schedulers_match_oracle(name, ref_cls, n):
+    """The other five names of `models/stable_diffusion.py:199-227`: product (torch host code) vs the oracle's
+    independent numpy float64 restatement, whole trajectories; the stochastic ones get the same noise."""
+    kw = {"timestep_spacing": "leading"}
+    prod = schedulers.REGISTRY[name](schedulers.DDIMScheduler(**kw).config)
+    ref = ref_cls()
+    prod.set_timesteps(n)
+    ts = ref.set_timesteps(n)
+    assert np.allclose(prod.timesteps.double().numpy(), np.asarray(ts, dtype=np.float64)), (prod.timesteps, ts)
+    assert abs(float(prod.init_noise_sigma) - float(ref.init_noise_sigma)) < 1e-6
+    stochastic = name in ("euler_a", "DPM++ 2M SDE Karras")
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(2, 4, 8, 8, generator=g).double() * float(ref.init_noise_sigma)
+    xr = x.numpy().copy()
+    for t in prod.timesteps:
+        eps = torch.randn(2, 4, 8, 8, generator=g).double()
+        assert np.allclose(prod.scale_model_input(x, t).numpy(), ref.scale_model_input(xr, float(t)), atol=5e-5)
+        if stochastic:
+            z = torch.randn(2, 4, 8, 8, generator=g).double()
+            x = prod.step(eps, t, x, noise=z)[0]
+            xr = ref.step(eps.numpy(), float(t), xr, z.numpy())
+        else:
+            x = prod.step(eps, t, x)[0]
+            xr = ref.step(eps.numpy(), float(t), xr)
+        assert np.allclose(x.numpy(), xr, atol=5e-5), (name, float(t), np.abs(x.numpy() - xr).max())
+
+
+def test_registry_has_the_references_eight_names_and_stochastic_steps_draw_noise():
+    assert sorted(schedulers.REGISTRY) == sorted(["DDIM", "euler", "euler_a", "DPM++ 2M", "DPM++ 2M Karras",
+                                                   "DPM++ 2M SDE Karras", "PNDM", "uni_pc"])
+    s = schedulers.REGISTRY["euler_a"](schedulers.DDIMScheduler().config)
+    s.set_timesteps(4)
+    x = torch.ones(1, 4, 4, 4)
+    a = s.step(torch.zeros_like(x), s.timesteps[0], x, generator=torch.Generator().manual_seed(1))[0]
+    s.set_timesteps(4)
+    b = s.step(torch.zeros_like(x), s.timesteps[0], x, generator=torch.Generator().manual_seed(2))[0]
+    assert not torch.equal(a, b)                       # sigma_up * noise really enters
+    assert not getattr(s, "supports_fused", True)      # the pipeline keeps it on the host path
+
+
 def test_pipeline_host_logic_matches_oracle_loop(golden):
     """StableDiffusionUnifiedPipeline (product host code) driving oracle-backed doubles must equal
     the oracle's own loop: checks CFG order, scheduler wiring, un-scaling and decode call."""
