@@ -119,6 +119,11 @@ class HipUNet2DConditionModel:
         self._finalized = True
         return self
 
+    def rebuild(self, state_dict: Dict[str, torch.Tensor]):
+        """A fresh engine of the same configuration on the same device with other weights (LoRA re-fuse:
+        the packed weights are immutable once finalized)."""
+        return type(self)(self.cfg, self.device).load_state_dict(state_dict)
+
     def memory(self):
         w, s = C.c_int64(), C.c_int64()
         _lib.check(self._lib.sd_unet_memory(self._h, C.byref(w), C.byref(s)), "sd_unet_memory")

@@ -26,6 +26,7 @@ from typing import Any, Dict, List, Optional, Union
 import torch
 
 from . import schedulers as _sched
+from .image_processor import VaeImageProcessor
 
 
 class SDModelWrapper:
@@ -33,8 +34,12 @@ class SDModelWrapper:
 
     def __init__(self, base=None, vae=None, text_encoder=None, tokenizer=None, scheduler=None,
                  text_encoder_2=None, tokenizer_2=None, model_type: str = "sd15", device: str = "cuda",
-                 model_name: Optional[str] = None):
+                 model_name: Optional[str] = None, unet_state_dict: Optional[Dict[str, torch.Tensor]] = None):
         self.base = base
+        # host copy of the UNet weights the LoRA adapters are folded into (load_lora_weights); the engine
+        # itself keeps only its packed device copy
+        self._lora = None
+        self._unet_sd = unet_state_dict
         self.vae = vae
         self.text_encoder = text_encoder
         self.tokenizer = tokenizer
@@ -48,6 +53,10 @@ class SDModelWrapper:
         if isinstance(self.scheduler, _sched.EulerDiscreteScheduler):
             self.scheduler_name = "euler"
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        # models/stable_diffusion.py:96-101
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
+        self.mask_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_normalize=False,
+                                                do_binarize=True, do_convert_grayscale=True)
         self.device = torch.device(device)
         self.type = model_type
         self.name = model_name
@@ -61,6 +70,46 @@ class SDModelWrapper:
         if getattr(self, "text_encoder_2", None) is not None:
             self.text_encoder_2.to(device)
         self.device = torch.device(device)
+
+    # ---- LoRA adapters (models/stable_diffusion.py:229-335), folded into the weights on the host ----
+    def _adapters(self):
+        if self._lora is None:
+            if self._unet_sd is None:
+                raise ValueError("LoRA needs the UNet's base weights on the host: build the wrapper with "
+                                 "unet_state_dict=... (the engine keeps only its packed device copy)")
+            from .lora import LoraAdapters
+            self._lora = LoraAdapters(self._unet_sd)
+        return self._lora
+
+    def _refuse(self):
+        if not hasattr(self.base, "rebuild"):
+            raise ValueError(f"{type(self.base).__name__} cannot be rebuilt from a state dict")
+        self.base = self.base.rebuild(self._adapters().fused())
+
+    def load_lora_weights(self, pretrained_model_name_or_path_or_dict, adapter_name: Optional[str] = None, **kwargs):
+        """`pytorch_lora_weights.safetensors` (a file, a folder holding one, or a dict) -> a named adapter,
+        active at weight 1 as in diffusers; `set_adapters` changes names / weights."""
+        self._adapters().load(pretrained_model_name_or_path_or_dict, adapter_name)
+        self._refuse()
+
+    def set_adapters(self, adapter_names, adapter_weights=None):
+        self._adapters().set(adapter_names, adapter_weights)
+        self._refuse()
+
+    def delete_adapters(self, adapter_names):
+        self._adapters().delete(adapter_names)
+        self._refuse()
+
+    def get_list_adapters(self):
+        return {"base": self._lora.names()} if self._lora is not None and self._lora.names() else {}
+
+    def set_lora_scale(self, scale: float):
+        """`cross_attention_kwargs={"scale": s}` (sd_unified_pipeline.py:190): a run-time multiplier on every
+        active adapter in diffusers; here a re-fuse, done only when the value changes."""
+        if self._lora is None or not self._lora.names() or float(scale) == self._lora.scale:
+            return
+        self._lora.scale = float(scale)
+        self._refuse()
 
     def set_scheduler(self, scheduler_name):
         """Registry of models/stable_diffusion.py:199-227 (names the engine's host code implements)."""
@@ -150,15 +199,15 @@ class StableDiffusionUnifiedPipeline:
         if model.device != self.device:
             model.to(self.device)
         self.model = model
-        if padding_mask_crop is not None:
-            raise NotImplementedError("padding_mask_crop needs the PIL image processor; pass pre-cropped tensors")
-
-        if isinstance(image, torch.Tensor) and image.shape[1] != 4:
-            # no PIL resize here: a pixel-space tensor fixes the working resolution
-            # (the reference resizes the image to height x width instead, :238 / :277-279)
-            if (height and height != image.shape[-2]) or (width and width != image.shape[-1]):
-                raise ValueError("height / width must match the image tensor (tensors are not resized)")
-            height, width = image.shape[-2], image.shape[-1]
+        if cross_attention_kwargs is not None and cross_attention_kwargs.get("scale", None) is not None \
+                and hasattr(model, "set_lora_scale"):
+            model.set_lora_scale(cross_attention_kwargs["scale"])      # `:190`: the LoRA scale of this call
+        if image is not None and mask_image is None:
+            # img2img keeps the image's own size (`:238` preprocesses without height / width); PIL, numpy and
+            # tensor inputs alike go through the image processor (rounded down to a multiple of the VAE factor)
+            image = model.image_processor.preprocess(image)
+            if image.shape[1] != 4:
+                height, width = image.shape[-2], image.shape[-1]
         height = height or model.base.config.sample_size * model.vae_scale_factor
         width = width or model.base.config.sample_size * model.vae_scale_factor
 
@@ -193,12 +242,17 @@ class StableDiffusionUnifiedPipeline:
             latents = self.prepare_latents_txt2img(shape, prompt_embeds.dtype, seed, latents)
         elif mask_image is not None:
             # ---- inpaint (:268-380) ----
-            if not isinstance(image, torch.Tensor) or not isinstance(mask_image, torch.Tensor):
-                raise ValueError("inpainting takes torch tensors: image [B,3|4,H,W] in [-1,1], mask [B,1,H,W] in [0,1]")
-            init_image = image.to(torch.float32)
-            mask = (mask_image.to(torch.float32) >= 0.5).to(torch.float32)       # mask_processor: do_binarize
-            if mask.ndim == 3:
-                mask = mask[:, None]
+            if padding_mask_crop is not None:           # `:270-275`: work on the masked region only
+                crops_coords = model.mask_processor.get_crop_region(mask_image, width, height, pad=padding_mask_crop)
+                resize_mode = "fill"
+            else:
+                crops_coords, resize_mode = None, "default"
+            latent_input = isinstance(image, torch.Tensor) and image.ndim == 4 and image.shape[1] == 4
+            init_image = model.image_processor.preprocess(
+                image, height=None if latent_input else height, width=None if latent_input else width,
+                crops_coords=crops_coords, resize_mode=resize_mode).to(torch.float32)
+            mask = model.mask_processor.preprocess(mask_image, height=height, width=width, resize_mode=resize_mode,
+                                                   crops_coords=crops_coords)
             if masked_image_latents is not None:
                 masked_image = masked_image_latents
             elif init_image.shape[1] == 4:

@@ -20,6 +20,9 @@ class OracleUNet:
     def to(self, *a, **k):
         return self
 
+    def rebuild(self, sd):
+        return OracleUNet(self.cfg, sd)
+
     def __call__(self, sample, t, ehs, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=False):
         return (unet_ref.unet_forward(self.cfg, self.sd, sample.float(), t, ehs.float(), added_cond_kwargs),)
 

@@ -296,15 +296,15 @@ def test_pipeline_inpaint(golden):
     image = torch.randn(1, 3, 64, 64, generator=g).clamp(-1, 1)
     mask = torch.zeros(1, 1, 64, 64)
     mask[:, :, :, 32:] = 1.0                                  # repaint the right half
+    # like the reference (:176-177, :278-285) the inpaint branch resizes image and mask to height x width,
+    # which default to sample_size * 8: the working size is passed explicitly
     out = pipe(model, prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask,
-               num_inference_steps=3, seed=1)
+               num_inference_steps=3, seed=1, height=64, width=64)
     assert out.shape == (1, 4, 8, 8) and torch.isfinite(out).all()
     gen = torch.Generator().manual_seed(1)
     ref_lat = model.vae.encode(image).latent_dist.sample(gen) * vcfg.scaling_factor
     assert torch.allclose(out[..., :4], ref_lat[..., :4], atol=1e-5)       # kept region == encoded original
     assert not torch.allclose(out[..., 4:], ref_lat[..., 4:], atol=1e-2)    # repainted region changed
-    with pytest.raises(NotImplementedError):
-        pipe(model, prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask, padding_mask_crop=8)
     with pytest.raises(ValueError):
         pipe(model, prompt_embeds=pos, negative_prompt_embeds=neg, image=image, mask_image=mask, strength=0.1,
-             num_inference_steps=3)                            # int(3 * 0.1) = 0 steps
+             num_inference_steps=3, height=64, width=64)      # int(3 * 0.1) = 0 steps
