@@ -420,11 +420,10 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, 
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int DT = (D + 15) / 16 + ((D % 16 == 0 && D <= 64) ? 1 : 0);
     constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT, PRESC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     // q_has_scale with the general kernel: the scores only need the running-max subtraction
     const float scale_log2e = q_has_scale ? 1.0f : 1.4426950408889634f / sqrtf((float)D);

@@ -32,6 +32,13 @@ bool bad_cfg(const sd_unet_config* c) {
         if ((c->down_block_has_attn[i] || c->up_block_has_attn[c->num_blocks - 1 - i]) &&
             !attention_supported(c->block_out_channels[i] / c->num_heads[i])) return true;
     }
+    if (c->addition_time_embed_dim > 0) {
+        // text_time conditioning: add_embedding.linear_1 reads [pooled text | 6 sinusoids of `ad`] rows of
+        // projection_class_embeddings_input_dim halves with 16-byte loads against weight rows packed to a
+        // multiple of 64 (UNet::run): anything else reads misaligned / wrong rows silently
+        const int ad = c->addition_time_embed_dim, pin = c->projection_class_embeddings_input_dim;
+        if ((ad & 1) || pin % 64 != 0 || pin - 6 * ad <= 0) return true;
+    }
     return c->cross_attention_dim % 64 != 0 || c->in_channels <= 0 || c->in_channels > 16;
 }
 
@@ -48,7 +55,8 @@ int sd_unet_create(const sd_unet_config* cfg, sd_unet** out) {
     if (!out) { set_error("null out"); return SD_ERR_INVALID; }
     if (bad_cfg(cfg)) {
         set_error("sd_unet_create: unsupported config (channels must be multiples of 64 and of the group "
-                  "count, head dims in {32,40,64,80,128,160}, cross_attention_dim % 64 == 0)");
+                  "count, head dims in {32,40,64,80,128,160}, cross_attention_dim % 64 == 0, text_time: even "
+                  "addition_time_embed_dim and projection_class_embeddings_input_dim % 64 == 0 and > 6 x it)");
         return SD_ERR_UNSUPPORTED;
     }
     *out = new (std::nothrow) sd_unet(*cfg);
@@ -247,6 +255,19 @@ int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries) {
 
 // ------------------------------------------------------------------------- single-operator entries
 // Test / tuner path only: packs the weight on every call (allocation + sync); never used by the models.
+// Device buffers of the single-operator entries: freed on every return path (hipFree waits for the device),
+// including the SD_HIP_CHECK early returns.
+struct DevScope {
+    std::vector<void*> bufs;
+    ~DevScope() { for (void* p : bufs) (void)hipFree(p); }
+    void drop(void* p) { for (auto& b : bufs) if (b == p) { (void)hipFree(b); b = nullptr; } }
+};
+#define SD_DEV_ALLOC(scope, ptr, bytes)                                              \
+    do {                                                                             \
+        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes)));          \
+        (scope).bufs.push_back(ptr);                                                 \
+    } while (0)
+
 // Optional GroupNorm behind the convolution (sd_op_conv2d_groupnorm): the conv's epilogue leaves the
 // GroupNorm summaries when the launch can (igemm2_emits_gnstats), the GroupNorm then skips its own pass.
 struct GnTail {
@@ -260,10 +281,11 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
     const long K = (long)ksize * ksize * Cin;
     if (K % 64 != 0 || Cin % 64 != 0) { set_error("sd_op_conv2d: Cin must be a multiple of 64"); return SD_ERR_INVALID; }
     const long rows = (Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    DevScope scope;
     half_t* wp = nullptr;
     float* bp = nullptr;
-    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), (size_t)rows * K * sizeof(half_t)));
-    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bp), (size_t)rows * sizeof(float)));
+    SD_DEV_ALLOC(scope, wp, (size_t)rows * K * sizeof(half_t));
+    SD_DEV_ALLOC(scope, bp, (size_t)rows * sizeof(float));
     SD_HIP_CHECK(hipMemsetAsync(wp, 0, (size_t)rows * K * sizeof(half_t), s));
     SD_HIP_CHECK(hipMemsetAsync(bp, 0, (size_t)rows * sizeof(float), s));
     int rc = launch_pack_conv(static_cast<const half_t*>(w_oihw), wp, Cout, Cin, ksize, ksize, K, s);
@@ -272,8 +294,8 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
     if (!rc && geglu) {
         // interleave hidden / gate rows per 64 exactly as WeightStore::pack_geglu does
         half_t* wg = nullptr; float* bg = nullptr;
-        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wg), (size_t)rows * K * sizeof(half_t)));
-        SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bg), (size_t)rows * sizeof(float)));
+        SD_DEV_ALLOC(scope, wg, (size_t)rows * K * sizeof(half_t));
+        SD_DEV_ALLOC(scope, bg, (size_t)rows * sizeof(float));
         SD_HIP_CHECK(hipMemsetAsync(wg, 0, (size_t)rows * K * sizeof(half_t), s));
         SD_HIP_CHECK(hipMemsetAsync(bg, 0, (size_t)rows * sizeof(float), s));
         const long half_rows = Cout / 2;
@@ -284,7 +306,7 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
             SD_HIP_CHECK(hipMemcpyAsync(bg + blk * 128 + 64, bp + half_rows + blk * 64, 64 * 4, hipMemcpyDeviceToDevice, s));
         }
         SD_HIP_CHECK(hipStreamSynchronize(s));
-        (void)hipFree(wp); (void)hipFree(bp);
+        scope.drop(wp); scope.drop(bp);
         wp = wg; bp = bg;
     }
     float* partial = nullptr;
@@ -305,7 +327,7 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
         const bool v2 = igemm2_supported(p);
         if (v2) {
             const long pf = igemm2_partial_floats(p);
-            if (pf > 0) SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&partial), (size_t)pf * sizeof(float)));
+            if (pf > 0) SD_DEV_ALLOC(scope, partial, (size_t)pf * sizeof(float));
         }
         float* gnbuf = nullptr;
         float* gnscratch = nullptr;
@@ -313,9 +335,9 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
         if (gn) {
             int rows = 0;
             if (gn->fused) *gn->fused = 0;
-            SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gnscratch), (size_t)gn_scratch_floats(N, (long)p.OH * p.OW, Cout, gn->groups) * 4));
+            SD_DEV_ALLOC(scope, gnscratch, (size_t)gn_scratch_floats(N, (long)p.OH * p.OW, Cout, gn->groups) * 4);
             if (igemm2_emits_gnstats(p, gn->groups, &rows)) {
-                SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&gnbuf), (size_t)gnstat_floats(N, (long)p.OH * p.OW, gn->groups) * 4));
+                SD_DEV_ALLOC(scope, gnbuf, (size_t)gnstat_floats(N, (long)p.OH * p.OW, gn->groups) * 4);
                 p.gnstat_out = gnbuf; p.gn_groups = gn->groups;
                 gst.part = gnbuf; gst.rows = rows; gst.S = p.OH * p.OW / rows;
                 if (gn->fused) *gn->fused = 1;
@@ -328,7 +350,7 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
         // weights per forward never stay in the 256 MB Infinity Cache); unset = same buffer every launch.
         half_t* res_bench = nullptr;   // SD_BENCH_RES=1 (tuner): time the launch with the fused residual add
         if (ms_out && !res && getenv("SD_BENCH_RES")) {
-            SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&res_bench), (size_t)p.M * ocols * sizeof(half_t)));
+            SD_DEV_ALLOC(scope, res_bench, (size_t)p.M * ocols * sizeof(half_t));
             SD_HIP_CHECK(hipMemsetAsync(res_bench, 0, (size_t)p.M * ocols * sizeof(half_t), s));
             p.res = res_bench;
         }
@@ -342,7 +364,7 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
                 nrot = ((long)mb * 1000000L + (long)wbytes - 1) / (long)wbytes;
                 if (nrot > iters + 2) nrot = iters + 2;
                 if (nrot > 1) {
-                    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wring), wbytes * (size_t)nrot));
+                    SD_DEV_ALLOC(scope, wring, wbytes * (size_t)nrot);
                     for (long r = 0; r < nrot; ++r)
                         SD_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(wring) + wbytes * (size_t)r, wp, wbytes,
                                                     hipMemcpyDeviceToDevice, s));
@@ -357,7 +379,7 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
         if (gn && !rc)
             rc = launch_groupnorm(p.y, p.ldy, gn->gamma, gn->beta, static_cast<half_t*>(gn->y), Cout, N, (long)p.OH * p.OW, Cout,
                                   gn->groups, gn->eps, gn->silu, gnscratch, s, gst.part ? &gst : nullptr);
-        if (gn) { (void)hipStreamSynchronize(s); if (gnbuf) (void)hipFree(gnbuf); (void)hipFree(gnscratch); }
+        if (gn) (void)hipStreamSynchronize(s);
         if (ms_out && !rc) {
             SD_HIP_CHECK(hipEventRecord(e1, s));
             SD_HIP_CHECK(hipEventSynchronize(e1));
@@ -366,12 +388,9 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
             *ms_out = ms / (float)iters;
         }
         if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-        if (wring) { (void)hipStreamSynchronize(s); (void)hipFree(wring); }
-        if (res_bench) { (void)hipStreamSynchronize(s); (void)hipFree(res_bench); }
+        if (wring || res_bench) (void)hipStreamSynchronize(s);
     }
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(wp); (void)hipFree(bp);
-    if (partial) (void)hipFree(partial);
     if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
     return rc;
 }
@@ -403,13 +422,13 @@ int sd_bench_conv2d(const void* x, const void* w_oihw, void* y, int N, int H, in
 int sd_op_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int N, int HW, int C,
                     int groups, float eps, int silu, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
+    DevScope scope;
     float* scratch = nullptr;
-    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t)gn_scratch_floats(N, HW, C, groups) * 4));
+    SD_DEV_ALLOC(scope, scratch, (size_t)gn_scratch_floats(N, HW, C, groups) * 4);
     int rc = launch_groupnorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),
                               static_cast<const float*>(beta_f32), static_cast<half_t*>(y), C, N, HW, C, groups,
                               eps, silu, scratch, s);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(scratch);
     if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
     return rc;
 }
@@ -418,8 +437,9 @@ int sd_bench_groupnorm(const void* x, const void* gamma_f32, const void* beta_f3
                        int groups, float eps, int silu, int iters, float* ms_per_launch, void* stream) {
     if (iters < 1 || !ms_per_launch) { set_error("sd_bench_groupnorm: bad arguments"); return SD_ERR_INVALID; }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    DevScope scope;
     float* scratch = nullptr;
-    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch), (size_t)gn_scratch_floats(N, HW, C, groups) * 4));
+    SD_DEV_ALLOC(scope, scratch, (size_t)gn_scratch_floats(N, HW, C, groups) * 4);
     hipEvent_t e0, e1;
     SD_HIP_CHECK(hipEventCreate(&e0));
     SD_HIP_CHECK(hipEventCreate(&e1));
@@ -437,7 +457,6 @@ int sd_bench_groupnorm(const void* x, const void* gamma_f32, const void* beta_f3
     *ms_per_launch = ms / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    (void)hipFree(scratch);
     if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
     return rc;
 }

@@ -20,6 +20,21 @@ void set_error(const std::string& msg);
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: one process may drive engines on several
+// GPUs (HipUNet2DConditionModel(device="cuda:1")), so "already set" is remembered per (launcher, device).
+// Setting it twice is harmless, so a racy first call from two threads only costs a repeat.
+struct PerDeviceOnce {
+    unsigned long long done = 0;
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        const bool was = (done & bit) != 0;
+        done |= bit;
+        return !was;
+    }
+};
+
 }  // namespace sd
 
 #define SD_HIP_CHECK(expr)                                                              \

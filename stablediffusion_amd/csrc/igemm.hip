@@ -235,11 +235,10 @@ int launch_cfg(const IGemmParams& p, hipStream_t s) {
     constexpr size_t stage = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
     constexpr size_t epi = (size_t)BM * (BN + 8) * sizeof(half_t);
     constexpr size_t lds = stage > epi ? stage : epi;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), lds, s, p);

@@ -829,7 +829,10 @@ bool halo_supported(const IGemmParams& p) {
 int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     const int Wt = halo_patch_width(p.H, p.W), R = 256 / Wt;
     const size_t lds = (size_t)2 * (R + 2) * (Wt + 2) * 128 + (size_t)3 * 160 * 128;
-    static size_t attr = 0;
+    static size_t attr_by_dev[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& attr = attr_by_dev[dev & 63];
     if (lds > attr) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -858,11 +861,10 @@ template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG, int BK
 int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     constexpr size_t lds = IGemm2Lds<BM, BN, STAGES, BKT>::TOTAL;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     const int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
     const int nk = p.K / BKT;

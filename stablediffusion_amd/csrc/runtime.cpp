@@ -1,7 +1,9 @@
 // Arena, weight store and op wrappers of the denoise engine (host side, HIP runtime only).
 #include "engine.h"
 
+#include <atomic>
 #include <cstdio>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 
@@ -258,8 +260,11 @@ int WeightStore::fold_ln(ConvW* w, const NormW& ln, int rows_scaled, float row_s
 
 // ---------------------------------------------------------------------------------------- profiler
 namespace {
+// The profiler is process-wide (bench.py brackets one forward at a time); the record list is guarded so that
+// two handles driven from two threads cannot corrupt it -- their rows would interleave, nothing worse.
 struct ProfRec { std::string name; double flops, bytes; hipEvent_t a, b; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 }  // namespace
 void prof_enable(bool on) { g_prof_on = on; }
@@ -269,14 +274,18 @@ void prof_open(hipStream_t s, const char* kernel, double flops, double bytes) {
     ProfRec r{kernel, flops, bytes, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
 }
 void prof_close(hipStream_t s) {
-    if (!g_prof_on || g_prof.empty()) return;
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.empty()) return;
     (void)hipEventRecord(g_prof.back().b, s);
 }
 int prof_collect(std::map<std::string, ProfAgg>* out) {
     SD_HIP_CHECK(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {

@@ -260,8 +260,9 @@ class HipAutoencoderKL:
 
     def to(self, device=None, dtype=None):
         # the reference flips the VAE to fp32 around encode when force_upcast is set
-        # (sd_unified_pipeline.py:1020-1036); the engine keeps fp32 accumulators and statistics
-        # internally, so dtype requests are accepted and ignored.
+        # (sd_unified_pipeline.py:1020-1036); the engine keeps fp32 accumulators and statistics but fp16
+        # activations, so dtype requests are accepted and ignored, and encode_moments raises if a
+        # force_upcast VAE really overflows (see there).
         if device is not None and not isinstance(device, torch.dtype) and torch.device(device).type != "cuda":
             raise _lib.EngineError("HipAutoencoderKL lives on the HIP device only")
         return self
@@ -296,6 +297,13 @@ class HipAutoencoderKL:
             rc = self._lib.sd_vae_encode(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(mom.data_ptr()), B, H, W,
                                          C.c_void_p(_stream_ptr()))
         _lib.check(rc, "sd_vae_encode")
+        if getattr(self.cfg, "force_upcast", False) and not bool(torch.isfinite(mom).all()):
+            # The reference runs the VAE in fp32 around encode when force_upcast is set
+            # (sd_unified_pipeline.py:1020-1036: the SDXL VAE overflows fp16 activations on some images).  The
+            # engine keeps fp32 accumulators and statistics but stores inter-layer activations in fp16: an
+            # overflow is reported, never passed on as inf / NaN latents (INTEGRATION.md "limits").
+            raise _lib.EngineError("VAE encode overflowed the engine's fp16 activations (config.force_upcast is set: "
+                                   "this VAE needs fp32 activations for this image); no latents were produced")
         return mom
 
     def encode(self, x, return_dict=True):
