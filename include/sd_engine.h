@@ -232,6 +232,11 @@ int sd_igemm_force(int variant, int splits);
 int sd_op_conv2d(const void* x_nhwc, const void* w_oihw, const void* bias, const void* rowadd,
                  const void* res_nhwc, void* y_nhwc, int N, int H, int W, int Cin, int Cout,
                  int ksize, int stride, int upsample2x, int geglu, void* stream);
+/* conv_out: 3x3 / stride 1 / pad 1 convolution to 1..4 output channels (UNet2DConditionModel.conv_out 320 -> 4,
+ * AutoencoderKL decoder.conv_out 128 -> 3; diffusers modules under sd_unified_pipeline.py:475-482, :523) with
+ * the NHWC -> NCHW change of layout fused: x NHWC f16, w OIHW f16, bias f32, y NCHW f16.  Cin % 64 == 0. */
+int sd_op_conv3x3_small_cout(const void* x_nhwc, const void* w_oihw, const void* bias, void* y_nchw, int N, int H,
+                             int W, int Cin, int Cout, void* stream);
 /* Convolution followed by GroupNorm (+ SiLU) of its output, the pair ResnetBlock2D issues as
  * conv1 -> norm2 and the VAE decoder as conv2 -> next norm1 (diffusers resnet.py under
  * sd_unified_pipeline.py:475-482, :523).  When the launch allows it the convolution's epilogue leaves

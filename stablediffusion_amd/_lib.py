@@ -116,6 +116,7 @@ SIGNATURES = {
     "sd_prof_enable": (_I, [_I]),
     "sd_prof_collect": (_I, [C.POINTER(SdProfEntry), _I, C.POINTER(_I)]),
     "sd_op_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sd_op_conv3x3_small_cout": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sd_op_conv2d_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
                                     C.POINTER(_I), _P]),
     "sd_bench_conv2d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _P]),

@@ -402,6 +402,24 @@ int sd_op_conv2d(const void* x, const void* w_oihw, const void* bias_f32, const 
                        stream, 1, nullptr);
 }
 
+int sd_op_conv3x3_small_cout(const void* x, const void* w_oihw, const void* bias_f32, void* y_nchw, int N, int H, int W,
+                             int Cin, int Cout, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cin % 64 != 0 || Cout < 1 || Cout > 4) { set_error("sd_op_conv3x3_small_cout: Cin % 64 == 0, Cout in 1..4"); return SD_ERR_INVALID; }
+    const long K = 9L * Cin;
+    DevScope scope;
+    half_t* wp = nullptr;
+    SD_DEV_ALLOC(scope, wp, (size_t)kWeightRowPad * K * sizeof(half_t));
+    SD_HIP_CHECK(hipMemsetAsync(wp, 0, (size_t)kWeightRowPad * K * sizeof(half_t), s));
+    int rc = launch_pack_conv(static_cast<const half_t*>(w_oihw), wp, Cout, Cin, 3, 3, K, s);
+    if (!rc)
+        rc = launch_conv3x3_small_cout(static_cast<const half_t*>(x), Cin, wp, K, static_cast<const float*>(bias_f32),
+                                       static_cast<half_t*>(y_nchw), N, H, W, Cin, Cout, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
 int sd_op_conv2d_groupnorm(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
                            void* y_conv, const void* gamma_f32, const void* beta_f32, void* y_gn, int N, int H, int W,
                            int Cin, int Cout, int ksize, int stride, int upsample2x, int groups, float eps, int silu,

@@ -908,11 +908,11 @@ int g_force_splits = 0;
 //   8 / 9: 128x64 / 128x160 with a 3-deep ring: only pays on the small-M, deep-K shapes of the 8x8 and
 //          16x16 levels when their weights come cold from HBM (as they do inside a forward); with the
 //          weights cache-resident the 2-deep rings win everywhere (tools/tune_igemm.py, SD_BENCH_COLD_MB)
-//   11 / 12: 128x64 with a 4- / 6-deep ring, 13: 64x64 6-deep, 14: 128x128 4-deep, 15: 128x160 4-deep.
-//          Grids of <= 2 blocks per CU (the 16x16 / 8x8-level linears: M = 512..2048) have no second block
-//          to hide a K step's L2 round trip behind: with prefetch distance 1 every 64-deep step costs
-//          that round trip (0.4-0.5 us against 0.12 us of MFMAs); a ring deep enough to keep 3-5 slabs
-//          in flight makes the loop MFMA-paced after the prologue.
+// Measured and dropped in round 2 (profiles/tune/r02_deep_rings.txt): 4- and 6-deep rings on 128x64 / 64x64 /
+// 128x128 / 128x160 tiles (one block per CU, 3-5 slabs in flight) for the small-grid linears of the 16x16 /
+// 8x8 levels: 0-60 % slower than the 2- / 3-deep rings at 2-3 blocks per CU on every UNet shape.  Those
+// launches are bound by the L2 -> LDS transfer rate per CU and by their prologue + epilogue, not by the
+// per-slab round trip a deeper ring hides.  (The ring-depth template parameter still goes to 8.)
 // printf formats of the kernel names as rocprofv3 prints them (%s = the pointwise flag)
 static const char* kIgemm2Names[] = {
     "igemm2_kernel<256,128,4,2,3,%s,false,64>", "igemm2_kernel<128,128,2,2,2,%s,false,64>",
@@ -920,11 +920,8 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
     "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
-    "conv3x3_halo_kernel",
-    "igemm2_kernel<128,64,2,2,4,%s,false,64>",  "igemm2_kernel<128,64,2,2,6,%s,false,64>",
-    "igemm2_kernel<64,64,2,2,6,%s,false,64>",   "igemm2_kernel<128,128,2,2,4,%s,false,64>",
-    "igemm2_kernel<128,160,2,2,4,%s,false,64>"};
-constexpr int kNumVariants = 16;
+    "conv3x3_halo_kernel"};
+constexpr int kNumVariants = 11;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -937,13 +934,12 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}, {256, 160},
-                                               {128, 64}, {128, 64}, {64, 64}, {128, 128}, {128, 160}};
+                                               {128, 64}, {128, 160}, {256, 160}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
 // Per-shape choices measured on MI355X by tools/tune_igemm.py (profiles/tune/*.json).
-struct TunedEntry { int M, N, K, ks, stride, up, geglu, variant, splits; };
+struct TunedEntry { int M, N, K, ks, stride, up, geglu, variant, splits; float us; int alt_variant; float alt_us; };
 static const TunedEntry kTuned[] = {
 #include "igemm2_table.inc"
 };
@@ -975,7 +971,10 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
     const int cpg = p.Cout / groups;
     if (!(cpg >= 8 || cpg == 4)) return false;          // a 16-byte chunk may touch at most two groups
     int v, sp;
-    igemm2_pick(p, &v, &sp);
+    IGemmParams q = p;                                  // the choice as it will be made WITH the summaries requested
+    static float sentinel;
+    q.gnstat_out = &sentinel;
+    igemm2_pick(q, &v, &sp);
     if (sp > 1) return false;
     if (v == 10 && !halo_supported(p)) v = 7;
     if (v == 10) return false;                          // see conv3x3_halo_kernel
@@ -992,7 +991,7 @@ static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
-        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6 && *variant != 14) *variant = 1;
+        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6) *variant = 1;
         if (p.geglu || p.act) *splits = 1;
         if (*variant == 10 && !halo_supported(p)) *variant = 7;
         return;
@@ -1002,6 +1001,13 @@ static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
             e.geglu == p.geglu) {
             *variant = e.variant; *splits = e.splits;
             if (*variant == 10 && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
+            // A GroupNorm reads this output: the halo kernel cannot leave the summaries (register ceiling), so
+            // it costs that GroupNorm its own statistics pass (~12 us + 1 us per 4 MB, measured); take the best
+            // tile that can, unless the halo kernel leads by more than that.
+            if (p.gnstat_out && *variant == 10 && e.alt_variant >= 0 &&
+                e.alt_us - e.us < 12.0f + (float)p.M * (float)p.Cout * 2.0f / 4.0e6f) {
+                *variant = e.alt_variant; *splits = 1;
+            }
             return;
         }
     const int nk = p.K / BK;
@@ -1058,11 +1064,6 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 8: return launch_v2<128, 64, 2, 2, 3>(p, partial, sp, s);
         case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
         case 10: return launch_halo(p, partial, sp, s);
-        case 11: return launch_v2<128, 64, 2, 2, 4>(p, partial, sp, s);
-        case 12: return launch_v2<128, 64, 2, 2, 6>(p, partial, sp, s);
-        case 13: return launch_v2<64, 64, 2, 2, 6>(p, partial, sp, s);
-        case 14: return launch_v2<128, 128, 2, 2, 4>(p, partial, sp, s);
-        case 15: return launch_v2<128, 160, 2, 2, 4>(p, partial, sp, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

@@ -129,6 +129,13 @@ int launch_nchw_to_nhwc(const half_t* x, half_t* y, long ldy, int N, long HW, in
 // Pointwise CxC conv on NCHW with tiny C (VAE post_quant_conv / quant_conv).
 int launch_pointwise_nchw(const half_t* x, const half_t* w, const float* bias, half_t* y, int N,
                           int Cin, int Cout, long HW, hipStream_t s);
+// 3x3 / stride 1 / pad 1 conv to Cout <= 4 channels (conv_out): x NHWC f16 (row stride ldx), packed weights
+// [>= Cout rows][K = 9 * Cin] (rows beyond Cout are the pack's zero padding), fp32 bias; output NCHW f16.
+// Worth it from about 128 K output pixels (512-pixel blocks: fewer leave most CUs idle; measured on C2: the
+// 32 K-pixel UNet conv_out is faster on the generic 64-column tile, the 1 M-pixel VAE conv_out 1.7x faster here).
+constexpr long kSmallCoutMinPixels = 131072;
+int launch_conv3x3_small_cout(const half_t* x, long ldx, const half_t* w, long K, const float* bias, half_t* y_nchw,
+                              int N, int H, int W, int Cin, int Cout, hipStream_t s);
 // Weight packing: OIHW -> [O][KH][KW][I(+pad)] rows; Kpad >= KH*KW*I.
 int launch_pack_conv(const half_t* w_oihw, half_t* wp, int O, int I, int KH, int KW, long Kpad,
                      hipStream_t s);

@@ -318,6 +318,95 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(half_t* __restrict__ w, lo
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// conv_out: 3x3 / stride 1 / pad 1 convolution to a handful of output channels (UNet 320 -> 4, VAE decoder
+// 128 -> 3; diffusers `conv_out` under sd_unified_pipeline.py:475-482 / :523), NHWC f16 in, NCHW f16 out.
+// HBM-bound (the input is read once: 268 MB for the 512 px VAE batch), not a matrix-core shape: a 16-column
+// MFMA tile would still waste 4-5x and the generic 64-column tile ran it at 21 TF/s / 0.79 TB/s (0.33 ms).
+// One thread = two neighbouring output pixels, all COUT channels; a block's 8 x 64 pixels share a
+// (10 x 66)-pixel halo tile of 32 input channels in LDS (pixel stride 80 B: conflict-free ds_read_b128 across
+// consecutive pixels); the slab's weights sit in LDS too and are read as broadcasts (a first version fed
+// them as scalar loads / SGPR operands: 140 exposed scalar-cache waits per slab made it slower than the
+// tile it replaced); v_dot2_f32_f16 with fp32 accumulation; the result goes straight out channel-major
+// (coalesced along W), so no NHWC -> NCHW pass follows.
+// Weights: the packed layout of pack_conv_kernel, K order [Cin/64][kh][kw][64].
+// ---------------------------------------------------------------------------------------------------
+constexpr int CO_TH = 8, CO_TW = 64;                      // output tile (rows x cols) per 256-thread block: 2 pixels per thread
+constexpr int CO_CS = 32;                                 // input channels per LDS slab
+constexpr int CO_PSTR = CO_CS + 8;                        // halo pixel stride in halves (80 B: conflict-free b128 reads)
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_cout_kernel(const half_t* __restrict__ x, long ldx,
+                                                                 const half_t* __restrict__ w, long K,
+                                                                 const float* __restrict__ bias,
+                                                                 half_t* __restrict__ y, int N, int H, int W, int Cin,
+                                                                 int cout_real) {
+    constexpr int HP = (CO_TH + 2) * (CO_TW + 2);
+    __shared__ __attribute__((aligned(16))) half_t halo[HP * CO_PSTR];
+    __shared__ __attribute__((aligned(16))) half_t wl[9 * (CO_CS / 8) * COUT * 8];      // [tap][chunk][co][8]
+    const int tid = threadIdx.x;
+    const int tiles_w = (W + CO_TW - 1) / CO_TW, tiles_h = (H + CO_TH - 1) / CO_TH;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int oh0 = th * CO_TH, ow0 = tw * CO_TW;
+    const int lr = tid / (CO_TW / 2), lc = (tid % (CO_TW / 2)) * 2;     // this thread's two pixels: (lr, lc), (lr, lc + 1)
+    float acc[2][COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) { acc[0][co] = 0.f; acc[1][co] = 0.f; }
+    const half_t* xn = x + (long)n * H * W * ldx;
+    for (int c0 = 0; c0 < Cin; c0 += CO_CS) {
+        __syncthreads();                                  // previous slab fully consumed
+        for (int i = tid; i < HP * (CO_CS / 8); i += 256) {       // halo pixel, 16-byte chunk
+            const int hp = i / (CO_CS / 8), ch = i % (CO_CS / 8);
+            const int hr = hp / (CO_TW + 2), hc = hp - hr * (CO_TW + 2);
+            const int ih = oh0 - 1 + hr, iw = ow0 - 1 + hc;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                v = *reinterpret_cast<const h8*>(xn + ((long)ih * W + iw) * ldx + c0 + ch * 8);
+            *reinterpret_cast<h8*>(halo + hp * CO_PSTR + ch * 8) = v;
+        }
+        // the slab's weights, packed K order [Cin / 64][tap][64]: this slab is the (c0 % 64)-th half of a 64-group
+        for (int i = tid; i < 9 * (CO_CS / 8) * COUT; i += 256) {
+            const int co = i % COUT, ch = (i / COUT) % (CO_CS / 8), tap = i / (COUT * (CO_CS / 8));
+            *reinterpret_cast<h8*>(wl + i * 8) =
+                *reinterpret_cast<const h8*>(w + (long)co * K + ((long)(c0 / 64) * 9 + tap) * 64 + (c0 % 64) + ch * 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const half_t* px = halo + ((lr + tap / 3) * (CO_TW + 2) + lc + tap % 3) * CO_PSTR;
+#pragma unroll
+            for (int ch = 0; ch < CO_CS / 8; ++ch) {
+                const h8 x0 = *reinterpret_cast<const h8*>(px + ch * 8);
+                const h8 x1 = *reinterpret_cast<const h8*>(px + CO_PSTR + ch * 8);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const h8 wv = *reinterpret_cast<const h8*>(wl + ((tap * (CO_CS / 8) + ch) * COUT + co) * 8);   // LDS broadcast
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const h2 wp = {wv[2 * e], wv[2 * e + 1]};
+                        acc[0][co] = __builtin_amdgcn_fdot2(h2{x0[2 * e], x0[2 * e + 1]}, wp, acc[0][co], false);
+                        acc[1][co] = __builtin_amdgcn_fdot2(h2{x1[2 * e], x1[2 * e + 1]}, wp, acc[1][co], false);
+                    }
+                }
+            }
+        }
+    }
+    const int oh = oh0 + lr;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+        const int ow = ow0 + lc + p2;
+        if (oh < H && ow < W) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co)
+                if (co < cout_real)
+                    y[(((long)n * cout_real + co) * H + oh) * W + ow] = (half_t)(acc[p2][co] + (bias ? bias[co] : 0.f));
+        }
+    }
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -374,6 +463,16 @@ int launch_pointwise_nchw(const half_t* x, const half_t* w, const float* bias, h
                           int Cout, long HW, hipStream_t s) {
     hipLaunchKernelGGL(pointwise_nchw_kernel, grid1d((long)N * Cout * HW), dim3(256), 0, s, x, w, bias, y, N,
                        Cin, Cout, HW);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_conv3x3_small_cout(const half_t* x, long ldx, const half_t* w, long K, const float* bias, half_t* y_nchw,
+                              int N, int H, int W, int Cin, int Cout, hipStream_t s) {
+    if (Cout < 1 || Cout > 4 || Cin % 64 != 0 || K != 9L * Cin) { set_error("conv3x3_small_cout: Cout in 1..4, Cin % 64 == 0"); return 1; }
+    const long tiles = (long)N * ((H + CO_TH - 1) / CO_TH) * ((W + CO_TW - 1) / CO_TW);
+    if (tiles == 0) return 0;
+    hipLaunchKernelGGL(conv3x3_small_cout_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, w, K, bias, y_nchw, N, H, W,
+                       Cin, Cout);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -559,9 +559,19 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         const long M = (long)B * h * w;
         View hn(a.alloc_h(M * C), C, C);
         op_groupnorm(c, norm_out, final_x, hn, B, (long)h * w, G, eps, 1, xs);
-        View y(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
-        op_conv(c, conv_out, hn, B, h, w, y);
-        if (go && !c.err) c.err = launch_nhwc_to_nchw(y.p, y.ld, out, B, (long)h * w, cfg.out_channels, s);
+        if (cfg.out_channels <= 4 && conv_out.ks == 3 && conv_out.K == 9L * C && M >= kSmallCoutMinPixels) {
+            // dedicated HBM-bound kernel, writes NCHW directly (kernels.h: launch_conv3x3_small_cout)
+            if (go && !c.err) {
+                prof_open(s, "conv3x3_small_cout_kernel", 2.0 * M * cfg.out_channels * 9.0 * C, 2.0 * M * (C + cfg.out_channels));
+                c.err = launch_conv3x3_small_cout(hn.p, hn.ld, conv_out.w, conv_out.K, conv_out.bias, out, B, h, w, C,
+                                                  cfg.out_channels, s);
+                prof_close(s);
+            }
+        } else {
+            View y(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
+            op_conv(c, conv_out, hn, B, h, w, y);
+            if (go && !c.err) c.err = launch_nhwc_to_nchw(y.p, y.ld, out, B, (long)h * w, cfg.out_channels, s);
+        }
     }
     return c.err;
 }

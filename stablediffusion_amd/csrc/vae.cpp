@@ -240,9 +240,18 @@ int VAE::run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w) {
         const int C = boc[0];
         View hn(a.alloc_h(M * C), C, C);
         op_groupnorm(c, d_norm_out, cur, hn, B, (long)h * w, G, kVaeEps, 1, xs);
-        View o(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
-        op_conv(c, d_conv_out, hn, B, h, w, o);
-        if (go && !c.err) c.err = launch_nhwc_to_nchw(o.p, o.ld, img, B, (long)h * w, cfg.out_channels, s);
+        if (cfg.out_channels <= 4 && d_conv_out.ks == 3 && d_conv_out.K == 9L * C && M >= kSmallCoutMinPixels) {
+            if (go && !c.err) {
+                prof_open(s, "conv3x3_small_cout_kernel", 2.0 * M * cfg.out_channels * 9.0 * C, 2.0 * M * (C + cfg.out_channels));
+                c.err = launch_conv3x3_small_cout(hn.p, hn.ld, d_conv_out.w, d_conv_out.K, d_conv_out.bias, img, B, h, w, C,
+                                                  cfg.out_channels, s);
+                prof_close(s);
+            }
+        } else {
+            View o(a.alloc_h(M * cfg.out_channels), cfg.out_channels, cfg.out_channels);
+            op_conv(c, d_conv_out, hn, B, h, w, o);
+            if (go && !c.err) c.err = launch_nhwc_to_nchw(o.p, o.ld, img, B, (long)h * w, cfg.out_channels, s);
+        }
     }
     return c.err;
 }
