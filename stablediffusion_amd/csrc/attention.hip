@@ -29,6 +29,8 @@
 //     64 queries per wave for d = 64 / 80 (slower); d = 40 runs 64 queries per wave (QT = 4).
 //   * head dims 40 / 80 / 160 (SD1.5), 64 (SDXL), 512 (VAE), 32 / 128 (test configs); the QK^T
 //     contraction is zero-padded to a multiple of 32, the PV row tiles to a multiple of 16.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sd {
@@ -37,6 +39,13 @@ namespace {
 [[maybe_unused]] constexpr float kRescaleThreshold = 8.0f;   // log2 units
 
 constexpr int odd32_bytes(int bytes) { return ((((bytes + 31) / 32) | 1)) * 32; }
+// LDS row stride of the K tile in halves.  d = 40 rows are stored DENSE (80 B): 16 consecutive rows at a
+// 20-dword stride start on 16 different bank quads, so the ds_read_b128 fragment reads stay conflict-free,
+// and the tile is 5 DMA pieces instead of 10 (half of the padded image was masked-off pad slots; the DMA
+// issue was 18 % of the kernel in a compile-time ablation).  The QK^T contraction still runs to 64: columns
+// 40..63 of a row are the next row's first values (the V tile's, after the last row) times the ZERO pad of
+// the query fragment.
+constexpr int k_row_halves(int D) { return D == 40 ? 40 : odd32_bytes((D + 31) / 32 * 32 * 2) / 2; }
 
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     // PV row tiles; head dims that fill their last tile (32, 64) get one more, so that the ones column
     // can ride there: 4 extra MFMAs per key tile buy back 32 v_add_f32 per lane (VALU issue is the limit)
     constexpr int DT = (D + 15) / 16 + ((D % 16 == 0 && D <= 64) ? 1 : 0);
-    constexpr int KSTR = odd32_bytes(DK * 2) / 2;        // halves
+    constexpr int KSTR = k_row_halves(D);                // halves
     constexpr int VSTR = odd32_bytes(DT * 16 * 2) / 2;   // halves
     constexpr int CH = D / 8;                            // real 16-byte chunks per row
     constexpr int NCH = KT * CH;                         // chunk slots per tile (K and V alike)
@@ -152,44 +161,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     //      out of range and land as zeros. ----
     constexpr unsigned kOOB = 0x80000000u;
     constexpr int SPRK = KSTR / 8, SPRV = VSTR / 8;           // 16-byte slots per padded row = DMA instrs per tile
-    constexpr int NKW = (SPRK + 3) / 4, NVW = (SPRV + 3) / 4; // per wave
+    // The tile's SPRK + SPRV pieces are dealt round-robin over the four waves as ONE list (K pieces first):
+    // with separate K and V lists wave 0 issued 4 of d = 40's 11 pieces and waves 2, 3 two each, and a
+    // piece's issue (60-185 cycles, MI355X_MICROARCH.md) sits on the wave's critical path.
+    constexpr int NP = SPRK + SPRV, NPW = (NP + 3) / 4;
+    const int wavu = __builtin_amdgcn_readfirstlane(wave);
     __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kb), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vb), 0, 0x7fffffff, 0x00020000);
-    int k_row[NKW], k_off[NKW], v_row[NVW], v_off[NVW];       // off < 0: pad chunk, lane sits out
+    int p_row[NPW], p_off[NPW];                               // off < 0: pad chunk, lane sits out
 #pragma unroll
-    for (int j = 0; j < NKW; ++j) {
-        const int p = (wave + 4 * j) * 64 + lane;
-        const int r = p / SPRK, c = p - r * SPRK;
-        k_row[j] = r;
-        k_off[j] = c < CH ? (int)((r * ldk + c * 8) * 2) : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < NVW; ++j) {
-        const int p = (wave + 4 * j) * 64 + lane;
-        const int r = p / SPRV, c = p - r * SPRV;
-        v_row[j] = r;
-        v_off[j] = c < CH ? (int)((r * ldv + c * 8) * 2) : -1;
+    for (int j = 0; j < NPW; ++j) {
+        const int q = wavu + 4 * j;                           // wave-uniform piece id
+        const bool isk = q < SPRK;
+        const int spr = isk ? SPRK : SPRV;
+        const int p = (isk ? q : q - SPRK) * 64 + lane;
+        const int r = p / spr, c = p - r * spr;
+        p_row[j] = r;
+        p_off[j] = c < CH ? (int)((r * (isk ? ldk : ldv) + c * 8) * 2) : -1;
     }
     auto issue_tile = [&](int bufi, int kt0) {
         half_t* dK = sK + bufi * TILE_HALVES;
         half_t* dV = sV + bufi * TILE_HALVES;
         const unsigned kbase = (unsigned)((long)kt0 * ldk * 2), vbase = (unsigned)((long)kt0 * ldv * 2);
+        const int lim = Tk - kt0;                             // rows of this tile that exist
 #pragma unroll
-        for (int j = 0; j < NKW; ++j) {
-            const int i = wave + 4 * j;
-            if (i < SPRK && k_off[j] >= 0) {
-                const unsigned voff = kt0 + k_row[j] < Tk ? kbase + (unsigned)k_off[j] : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(dK + i * 512), 16,
-                                                         voff, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NVW; ++j) {
-            const int i = wave + 4 * j;
-            if (i < SPRV && v_off[j] >= 0) {
-                const unsigned voff = kt0 + v_row[j] < Tk ? vbase + (unsigned)v_off[j] : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(dV + i * 512), 16,
-                                                         voff, 0, 0, 0);
+        for (int j = 0; j < NPW; ++j) {
+            const int q = wavu + 4 * j;
+            if (q < NP && p_off[j] >= 0) {
+                const bool isk = q < SPRK;
+                const unsigned voff = p_row[j] < lim ? (isk ? kbase : vbase) + (unsigned)p_off[j] : kOOB;
+                half_t* dst = isk ? dK + q * 512 : dV + (q - SPRK) * 512;
+                if (isk)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
             }
         }
     };
@@ -419,7 +424,7 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, 
                 int heads, long ldq, long ldk, long ldv, long ldo, int causal, bool q_has_scale, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32;
     constexpr int DT = (D + 15) / 16 + ((D % 16 == 0 && D <= 64) ? 1 : 0);
-    constexpr size_t lds = (size_t)KT * (odd32_bytes(DK * 2) + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
+    constexpr size_t lds = (size_t)KT * (k_row_halves(D) * 2 + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT, PRESC>),
@@ -452,6 +457,12 @@ int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* 
     case DD: return (prescaled && FAST) \
         ? launch_attn<DD, QQ, KK, FAST>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, true, s) \
         : launch_attn<DD, QQ, KK, false>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, prescaled != 0, s)
+    // Few, long query blocks leave CUs idle on the small maps (16 x 16 latents: 256 queries x 64 (batch, head)
+    // pairs = 128 blocks of 128 queries for 256 CUs): halve the block there.  (d = 40 was also tried at 48 / 32 /
+    // 16 queries per wave for more waves per SIMD: 299 -> 318 / 318 / 403 us on the 4096-token case: it is not
+    // latency-bound.)
+    if (d == 160 && (long)cdiv(Tq, 128) * B * heads < 256)
+        return launch_attn<160, 1, 64, false>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, prescaled != 0, s);
     switch (d) {
         SD_ATTN_CASE(32, 2, 64, true);
         SD_ATTN_CASE(40, 4, 64, true);
