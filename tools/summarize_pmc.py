@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE output (counter_collection.csv or the rocpd *_results.db; two separate passes) ->
-profiles/r01_pmc_hbm_traffic_per_launch.json, keyed by the kernel names bench.py reports.
+profiles/rNN_pmc_hbm_traffic_per_launch.json, keyed by the kernel names bench.py reports.
 FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of wide coalesced reads
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
 import collections
