@@ -905,6 +905,8 @@ int g_force_splits = 0;
 //   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
 //   6 / 7: 256x128 / 256x160, 8 waves, staggered DMA issue
 //   10: conv3x3_halo_kernel (256x160, A halo tile resident across the taps; 3x3 stride-1 convs, W in 16/32/64)
+//   11 / 12: 128x80 (4 x 1 waves, 2- / 3-deep ring): M = 2048, N = 1280 is exactly 256 such tiles -- one per CU at the
+//          least L2 -> LDS traffic a 256-tile grid can have there (133 MB against the 64x64 tile's 205 MB)
 //   8 / 9: 128x64 / 128x160 with a 3-deep ring: only pays on the small-M, deep-K shapes of the 8x8 and
 //          16x16 levels when their weights come cold from HBM (as they do inside a forward); with the
 //          weights cache-resident the 2-deep rings win everywhere (tools/tune_igemm.py, SD_BENCH_COLD_MB)
@@ -920,8 +922,9 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
     "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
-    "conv3x3_halo_kernel"};
-constexpr int kNumVariants = 11;
+    "conv3x3_halo_kernel",
+    "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>"};
+constexpr int kNumVariants = 13;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -934,7 +937,7 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}, {256, 160}};
+                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -1064,6 +1067,8 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 8: return launch_v2<128, 64, 2, 2, 3>(p, partial, sp, s);
         case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
         case 10: return launch_halo(p, partial, sp, s);
+        case 11: return launch_v2<128, 80, 4, 1, 2>(p, partial, sp, s);
+        case 12: return launch_v2<128, 80, 4, 1, 3>(p, partial, sp, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from stablediffusion_amd import _lib, config, shapes  # noqa: E402
 
 NAMES = ["256x128s3", "128x128s2", "128x160s2", "128x64s2", "64x64s2", "256x160s3", "256x128stag", "256x160w8",
-         "128x64s3", "128x160s3", "halo256x160"]
+         "128x64s3", "128x160s3", "halo256x160", "128x80s2", "128x80s3"]
 
 
 def main():
