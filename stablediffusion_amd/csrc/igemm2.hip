@@ -907,6 +907,8 @@ int g_force_splits = 0;
 //   10: conv3x3_halo_kernel (256x160, A halo tile resident across the taps; 3x3 stride-1 convs, W in 16/32/64)
 //   11 / 12: 128x80 (4 x 1 waves, 2- / 3-deep ring): M = 2048, N = 1280 is exactly 256 such tiles -- one per CU at the
 //          least L2 -> LDS traffic a 256-tile grid can have there (133 MB against the 64x64 tile's 205 MB)
+//   13 / 14: wsgemm.hip -- persistent, weight-stationary 128x160 / 128x128 (GEGLU) tiles for the K = 320 pointwise
+//          problems of the 64x64 level; taken whenever wsgemm_supported() (SD_NO_WSGEMM=1 turns that off)
 //   8 / 9: 128x64 / 128x160 with a 3-deep ring: only pays on the small-M, deep-K shapes of the 8x8 and
 //          16x16 levels when their weights come cold from HBM (as they do inside a forward); with the
 //          weights cache-resident the 2-deep rings win everywhere (tools/tune_igemm.py, SD_BENCH_COLD_MB)
@@ -923,8 +925,9 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
     "conv3x3_halo_kernel",
-    "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>"};
-constexpr int kNumVariants = 13;
+    "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>",
+    "wsgemm_kernel<160,false", "wsgemm_kernel<128,true"};
+constexpr int kNumVariants = 15;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -937,7 +940,7 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}};
+                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}, {128, 80}, {128, 128}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -953,16 +956,30 @@ static const TunedEntry kTuned[] = {
 // about two blocks per CU (512) are in flight, keeping >= 12 K-slabs per slice.
 static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits);
 
+static bool wsgemm_enabled() {
+    static const bool off = getenv("SD_NO_WSGEMM") != nullptr;
+    return !off;
+}
+
 void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     igemm2_pick_raw(p, variant, splits);
     if (p.ln_stat) *splits = 1;          // the LayerNorm correction lives in the fused epilogue only
+    const bool ws_ok = wsgemm_supported(p);
+    if (*variant >= 13 && !ws_ok) { *variant = p.geglu ? 1 : 2; *splits = 1; }     // (forced on a problem it does not take)
+    if (g_force_variant < 0 && ws_ok && wsgemm_enabled()) { *variant = p.geglu ? 14 : 13; *splits = 1; }
+    if (*variant == 13 && p.geglu) *variant = 14;
+    if (*variant == 14 && !p.geglu) *variant = 13;
 }
 
 bool igemm2_emits_rowstats(const IGemmParams& p, int* parts) {
     if (!igemm2_supported(p) || p.geglu) return false;
     int v, sp;
-    igemm2_pick(p, &v, &sp);
+    IGemmParams q = p;                                  // the choice as it will be made WITH the statistics requested
+    static float sentinel;
+    if (!q.rowstat_out) q.rowstat_out = &sentinel;
+    igemm2_pick(q, &v, &sp);
     if (sp > 1 || v == 10) return false;
+    if (v == 13) { *parts = wsgemm_rowstat_parts(p); return *parts <= kMaxLnParts; }
     int bm, bn;
     tile_dims(v, &bm, &bn);
     *parts = cdiv(p.Cout, bn);
@@ -978,7 +995,7 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
     static float sentinel;
     q.gnstat_out = &sentinel;
     igemm2_pick(q, &v, &sp);
-    if (sp > 1) return false;
+    if (sp > 1 || v >= 13) return false;
     if (v == 10 && !halo_supported(p)) v = 7;
     if (v == 10) return false;                          // see conv3x3_halo_kernel
     int bm, bn;
@@ -994,7 +1011,7 @@ static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
-        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6) *variant = 1;
+        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6 && *variant < 13) *variant = 1;
         if (p.geglu || p.act) *splits = 1;
         if (*variant == 10 && !halo_supported(p)) *variant = 7;
         return;
@@ -1069,6 +1086,8 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 10: return launch_halo(p, partial, sp, s);
         case 11: return launch_v2<128, 80, 4, 1, 2>(p, partial, sp, s);
         case 12: return launch_v2<128, 80, 4, 1, 3>(p, partial, sp, s);
+        case 13:
+        case 14: return launch_wsgemm(p, s);
         default: set_error("igemm2: bad variant"); return 1;
     }
 }

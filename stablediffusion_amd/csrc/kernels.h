@@ -67,6 +67,11 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s);
 void igemm2_force(int variant, int splits);            // tuner / tests: -1 restores the heuristic
 // Rows the packed weight matrix must be padded to (zero rows), so tile loads need no masks.
 constexpr int kWeightRowPad = 256;
+// Weight-stationary persistent GEMM for the K = 320 pointwise problems of the 64x64 level (wsgemm.hip):
+// igemm2 variants 13 (plain, 128x160) and 14 (GEGLU, 128x128); launch_igemm2 routes to it.
+bool wsgemm_supported(const IGemmParams& p);
+int wsgemm_rowstat_parts(const IGemmParams& p);         // column partials per row it writes to rowstat_out
+int launch_wsgemm(const IGemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Normalisation (norm.hip)

@@ -353,13 +353,6 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
     }
     const bool v2 = igemm2_supported(p);
     if (ln_in && !v2) { set_error("op_conv: the LayerNorm fold needs the LDS-DMA kernel"); c.err = 1; return; }
-    bool own_stats = false;      // the GEMM's epilogue writes the row statistics itself
-    if (stat_out) {
-        int parts = 1;
-        own_stats = igemm2_emits_rowstats(p, &parts);
-        stat_out->parts = own_stats ? parts : 1;
-        if (own_stats) p.rowstat_out = stat_out->p;
-    }
     if (gn_out) {
         int rows = 0;
         gn_out->st = GnStats();
@@ -370,6 +363,14 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
             gn_out->st.rows = rows;
             gn_out->st.S = p.OH * p.OW / rows;
         }
+    }
+    // (after the GroupNorm request: the tile choice, and with it the partial count, depends on it)
+    bool own_stats = false;      // the GEMM's epilogue writes the row statistics itself
+    if (stat_out) {
+        int parts = 1;
+        own_stats = igemm2_emits_rowstats(p, &parts);
+        stat_out->parts = own_stats ? parts : 1;
+        if (own_stats) p.rowstat_out = stat_out->p;
     }
     if (act && !v2) { set_error("op_conv: activation epilogue needs the LDS-DMA kernel (Cin % 64, Cout % 8)"); c.err = 1; return; }
     float* partial = nullptr;

@@ -347,3 +347,36 @@ def test_attention_prescaled_very_negative_scores(engine_lib):
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     assert rel_l2(out, ref) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(8, 64, 64, 320, 0, False), (8, 64, 64, 960, 0, False), (3, 64, 64, 320, 0, True),
+                                  (2, 64, 64, 640, 0, True), (1, 32, 32, 320, 0, False), (8, 64, 64, 2560, 1, False),
+                                  (5, 64, 48, 2560, 1, False), (2, 64, 64, 256, 1, False)])
+def test_weight_stationary_gemm(engine_lib, case):
+    """K = 320 pointwise problems with M % 128 == 0 go to wsgemm_kernel (persistent, weight-stationary; igemm2
+    variants 13 / 14): plain, residual and GEGLU epilogues against torch fp32, runs of one to twenty tiles per block
+    and W reloads inside a block (the LayerNorm-consumer and row-statistics forms run inside the UNet:
+    tests/test_fullsize_gpu.py)."""
+    N, H, W, Cout, geglu, res = case
+    Cin = 320
+    g = torch.Generator().manual_seed(Cout + N)
+    x = torch.randn(N, H, W, Cin, generator=g).half()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).half()
+    b = torch.randn(Cout, generator=g)
+    oc = Cout // 2 if geglu else Cout
+    r = torch.randn(N, H, W, oc, generator=g).half() if res else None
+    ref = F.linear(x.float(), w.float().view(Cout, Cin), b)
+    if geglu:
+        hh, gg = ref.chunk(2, dim=-1)
+        ref = hh * F.gelu(gg)
+    if res:
+        ref = ref.half().float() + r.float()
+    xd, wd, bd = h(x), h(w), b.cuda()
+    rd = h(r) if res else None
+    y = torch.zeros(N, H, W, oc, dtype=torch.float16, device="cuda")
+    rc = engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, P(rd) if res else None, P(y), N, H, W, Cin, Cout, 1, 1, 0, geglu,
+                                 stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 2e-3
