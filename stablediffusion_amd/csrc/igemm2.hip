@@ -966,7 +966,9 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     if (p.ln_stat) *splits = 1;          // the LayerNorm correction lives in the fused epilogue only
     const bool ws_ok = wsgemm_supported(p);
     if (*variant >= 13 && !ws_ok) { *variant = p.geglu ? 1 : 2; *splits = 1; }     // (forced on a problem it does not take)
-    if (g_force_variant < 0 && ws_ok && wsgemm_enabled()) { *variant = p.geglu ? 14 : 13; *splits = 1; }
+    // (with a residual the streamed tiles win by 1-6 us per launch -- profiles/r02_wsgemm.txt -- so those stay on them
+    // unless variant 13 is forced)
+    if (g_force_variant < 0 && ws_ok && !p.res && wsgemm_enabled()) { *variant = p.geglu ? 14 : 13; *splits = 1; }
     if (*variant == 13 && p.geglu) *variant = 14;
     if (*variant == 14 && !p.geglu) *variant = 13;
 }

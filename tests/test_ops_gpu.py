@@ -375,8 +375,12 @@ def test_weight_stationary_gemm(engine_lib, case):
     xd, wd, bd = h(x), h(w), b.cuda()
     rd = h(r) if res else None
     y = torch.zeros(N, H, W, oc, dtype=torch.float16, device="cuda")
-    rc = engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, P(rd) if res else None, P(y), N, H, W, Cin, Cout, 1, 1, 0, geglu,
-                                 stream())
+    engine_lib.sd_igemm_force(14 if geglu else 13, 1)      # (launches with a residual are not routed there by default)
+    try:
+        rc = engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, P(rd) if res else None, P(y), N, H, W, Cin, Cout, 1, 1, 0,
+                                     geglu, stream())
+    finally:
+        engine_lib.sd_igemm_force(-1, 0)
     assert rc == 0, engine_lib.sd_last_error()
     torch.cuda.synchronize()
     assert rel_l2(y, ref) < 2e-3
