@@ -926,7 +926,7 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
     "conv3x3_halo_kernel",
     "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>",
-    "wsgemm_kernel<160,false", "wsgemm_kernel<128,true"};
+    "wsgemm_kernel<160,false,...>", "wsgemm_kernel<128,true,...>"};
 constexpr int kNumVariants = 15;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
