@@ -258,6 +258,16 @@ int sd_op_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, voi
 int sd_bench_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
                        int N, int HW, int C, int groups, float eps, int silu, int iters,
                        float* ms_per_launch, void* stream);
+/* Timesteps / get_timestep_embedding as UNet2DConditionModel.time_proj and SDXL's add_time_proj issue it
+ * (diffusers embeddings.py under sd_unified_pipeline.py:475-482): out[b, :] = [cos(t_b f_i) | sin(t_b f_i)]
+ * (flip_sin_to_cos = 1) or [sin | cos], f_i = exp(-ln(1e4) i / (dim/2 - freq_shift)).  t, out: f32 device. */
+int sd_op_timestep_sinusoid(const float* t, float* out, int count, int dim, int flip_sin_to_cos, float freq_shift,
+                            void* stream);
+/* The small-batch linear of the time-embedding MLPs (TimestepEmbedding.linear_1 / linear_2, time_emb_proj):
+ * y[b, n] = act_out(bias[n] + sum_k act_in(x[b, k]) * W[n, k]), act = SiLU when the flag is set.  x, bias, y f32,
+ * W f16 row-major [n_out, k]. */
+int sd_op_small_linear(const float* x, const void* w_f16, const float* bias, float* y, int B, int K, int n_out,
+                       int silu_in, int silu_out, void* stream);
 /* LayerNorm over the last dim of [rows, C] f16. */
 int sd_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C,
                     float eps, void* stream);

@@ -479,6 +479,19 @@ int sd_bench_groupnorm(const void* x, const void* gamma_f32, const void* beta_f3
     return rc;
 }
 
+int sd_op_timestep_sinusoid(const float* t, float* out, int count, int dim, int flip_sin_to_cos, float freq_shift,
+                            void* stream) {
+    if (!t || !out || count < 1 || dim < 2 || (dim & 1)) { set_error("sd_op_timestep_sinusoid: bad arguments"); return SD_ERR_INVALID; }
+    return launch_timestep_sinusoid(t, 1, out, count, dim, flip_sin_to_cos, freq_shift, dim, static_cast<hipStream_t>(stream));
+}
+
+int sd_op_small_linear(const float* x, const void* w_f16, const float* bias, float* y, int B, int K, int n_out, int silu_in,
+                       int silu_out, void* stream) {
+    if (!x || !w_f16 || !y || B < 1 || K < 1 || n_out < 1) { set_error("sd_op_small_linear: bad arguments"); return SD_ERR_INVALID; }
+    return launch_small_linear(x, K, static_cast<const half_t*>(w_f16), bias, y, n_out, B, K, n_out, silu_in, silu_out,
+                               static_cast<hipStream_t>(stream));
+}
+
 int sd_op_layernorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int rows, int C, float eps,
                     void* stream) {
     return launch_layernorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),

@@ -384,3 +384,42 @@ def test_weight_stationary_gemm(engine_lib, case):
     assert rc == 0, engine_lib.sd_last_error()
     torch.cuda.synchronize()
     assert rel_l2(y, ref) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,flip,shift", [(320, 1, 0.0), (256, 1, 0.0), (320, 0, 1.0), (64, 0, 0.0)])
+def test_timestep_sinusoid(engine_lib, dim, flip, shift):
+    """`Timesteps` / get_timestep_embedding (time_proj of the UNet, add_time_proj of SDXL) against the oracle's
+    restatement: integer, fractional (Euler / DPM sigmas map to fractional timesteps) and large arguments."""
+    from oracle.unet_ref import timestep_sinusoid
+    t = torch.tensor([0.0, 1.0, 17.0, 250.5, 501.0, 980.9999, 999.0, 1024.0])
+    ref = timestep_sinusoid(t, dim, bool(flip), shift)
+    td = t.cuda()
+    out = torch.zeros(len(t), dim, dtype=torch.float32, device="cuda")
+    rc = engine_lib.sd_op_timestep_sinusoid(P(td), P(out), len(t), dim, flip, shift, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    # the arguments reach ~1e3 rad: fp32 range reduction on both sides, a few 1e-4 absolute
+    assert (out.cpu() - ref).abs().max() < 5e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,n_out,silu_in,silu_out", [(8, 320, 1280, 0, 1), (8, 1280, 1280, 0, 0), (2, 2816, 1280, 0, 1),
+                                                      (8, 1280, 320 * 22, 1, 0), (1, 64, 40, 1, 1)])
+def test_small_linear(engine_lib, B, K, n_out, silu_in, silu_out):
+    """The time-embedding MLP linears (TimestepEmbedding.linear_1 / linear_2, SDXL add_embedding, the stacked
+    time_emb_proj of every resnet): fp32 activations, fp16 weights, optional SiLU before / after."""
+    g = torch.Generator().manual_seed(K + n_out)
+    x = torch.randn(B, K, generator=g)
+    w = (torch.randn(n_out, K, generator=g) / K ** 0.5).half()
+    b = torch.randn(n_out, generator=g)
+    xi = F.silu(x) if silu_in else x
+    ref = F.linear(xi, w.float(), b)
+    if silu_out:
+        ref = F.silu(ref)
+    xd, wd, bd = x.cuda(), h(w), b.cuda()
+    y = torch.zeros(B, n_out, dtype=torch.float32, device="cuda")
+    rc = engine_lib.sd_op_small_linear(P(xd), P(wd), P(bd), P(y), B, K, n_out, silu_in, silu_out, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 1e-4
