@@ -576,19 +576,24 @@ __host__ __device__ inline int halo_patch_width(int H, int W) {
 // scratch and reloads them inside the main loop: 58.8 -> 72.7 us on the 64x64 320->320 conv, more than the
 // 19 us statistics pass it would save.  (Its 8 spilled dwords stay outside the loop; check
 // `scratch_` against the v_mfma range in the ISA after any change here.)
+template <int BN>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float* partial, int slabs_per_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(BN == 160 || BN == 128, "column tile");
     constexpr unsigned kOOB = 0x80000000u;
-    constexpr int BM = 256, BN = 160, NW = 8, NT = 512, WAVES_N = 2;
-    constexpr int WTM = 64, WTN = 80, TM = 4, TN = 5;
-    constexpr int B_INSTR = BN / 8, B_PW = 3, B_REM = B_INSTR % NW;      // 20 = 4 waves x 3 + 4 waves x 2
+    constexpr int BM = 256, NW = 8, NT = 512, WAVES_N = 2;
+    constexpr int WTM = 64, WTN = BN / 2, TM = 4, TN = WTN / 16;
+    constexpr int B_INSTR = BN / 8, B_PW = (B_INSTR + NW - 1) / NW, B_REM = B_INSTR % NW;   // 160: 20 = 4 waves x 3 + 4 x 2; 128: 2 each
     constexpr int B_STAGE_HALVES = BN * 64;     // three ring stages: one per tap of a kernel row
     constexpr int AJ = 7;                        // halo DMA instructions per wave, at most
     constexpr int LDC = BN + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // tile = an R x Wt patch of one image (Wt = the widest of 64 / 32 / 16 that divides W, R = 256 / Wt)
-    const int W = p.W, HW = p.H * p.W;
-    const int Wt = halo_patch_width(p.H, W), Wp = Wt + 2;
+    // (with the nearest-2x upsample fused in, the patch tiles the OUTPUT image and a halo pixel (ih, iw) of it reads
+    // input pixel (ih >> 1, iw >> 1): the upsampled tensor never exists)
+    const int W = p.OW, HW = p.OH * p.OW;                    // output image
+    const int IW = p.W, IHW = p.H * p.W;                     // input image
+    const int Wt = halo_patch_width(p.OH, W), Wp = Wt + 2;
     const int R = BM / Wt;
     const int HP = (R + 2) * Wp;                 // halo pixels per slab
     const int A_HALVES = HP * 64;
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     }
     const int n0 = tn * BN;
     const int split = blockIdx.y;
-    const int patches_w = W / Wt, patches = (p.H / R) * patches_w;
+    const int patches_w = W / Wt, patches = (p.OH / R) * patches_w;
     const int img = tm / patches, pidx = tm - img * patches;
     const int row0 = (pidx / patches_w) * R, col0 = (pidx % patches_w) * Wt;
     // GEMM row (NHWC pixel index) of the tile's local pixel ml
@@ -635,11 +640,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         const int hp = slot >> 3, cpos = slot & 7;
         const int hr = hp / Wp, hc = hp - hr * Wp;
         const int ih = row0 - 1 + hr, iw = col0 - 1 + hc;
-        const bool inb = ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)W);
+        const bool inb = ((unsigned)ih < (unsigned)p.OH) & ((unsigned)iw < (unsigned)W);
         const int chunk = cpos ^ (hp & 7);
         int off = -1;
         if (i < NI && slot < HP * 8)
-            off = inb ? (int)((((long)img * HW + (long)ih * W + iw) * p.ldx + chunk * 8) * 2) : -2;
+            off = inb ? (int)((((long)img * IHW + (long)(ih >> p.up) * IW + (iw >> p.up)) * p.ldx + chunk * 8) * 2) : -2;
         a_off[j] = off;
     }
     auto issueA = [&](int bufi, int slab) {
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     // ---- weight tile: 8 rows of 64 halves per DMA instruction, chunk ^ (row & 7) on the source side ----
     const int lrow = lane >> 3;
     const int chunkB = (lane & 7) ^ lrow;
-    const bool b_hi = wave < B_REM;                              // waves 0-3 issue 3, waves 4-7 issue 2
+    const bool b_hi = B_REM == 0 || wave < B_REM;                // 160: waves 0-3 issue 3, waves 4-7 issue 2
     const int b_cnt = b_hi ? B_PW : B_PW - 1;
     const int b_first = b_hi ? wave * B_PW : B_REM * B_PW + (wave - B_REM) * (B_PW - 1);
     unsigned b_off[B_PW];
@@ -806,6 +811,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
                                      : h8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    // GroupNorm summaries of the stored tile (as igemm2_kernel's epilogue) -- in the 128-column form only: with 64
+    // accumulator registers instead of 80 the allocator keeps the main loop free of spill reloads (the header
+    // comment has what happened at 160 columns)
+    constexpr bool GN = BN == 128;
+    const int cpg = (GN && p.gnstat_out) ? p.Cout / p.gn_groups : 8;
+    const int g_first = n / cpg;
+    const int gsplit = (g_first + 1) * cpg - n;
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int r = rr + it * RPP;
@@ -816,35 +829,54 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[it][e]);
             }
             *reinterpret_cast<h8*>(p.y + (long)row_of(r) * p.ldy + n) = v;
+            if (GN && p.gnstat_out) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    if (e < gsplit) { gs0 += f; gq0 += f * f; } else { gs1 += f; gq1 += f * f; }
+                }
+            }
+        }
+    }
+    if constexpr (GN) {
+        if (p.gnstat_out) {
+            float* sG = reinterpret_cast<float*>(smem + ((BM * LDC * 2 + 15) & ~15));     // behind the staging tile
+            gn_tile_stats<BM, BN, NT>(sG, tid, gs0, gq0, gs1, gq1, n0, p.Cout, cpg, p.gn_groups,
+                                      p.gnstat_out + ((long)img * patches + pidx) * p.gn_groups * 2);
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
 bool halo_supported(const IGemmParams& p) {
-    return p.KS == 3 && p.stride == 1 && p.up == 0 && p.pad == 1 && !p.geglu && !p.act && p.Cin % 64 == 0 &&
-           p.Cout % 8 == 0 && halo_patch_width(p.H, p.W) > 0 && p.OH == p.H && p.OW == p.W && p.K == 9 * p.Cin;
+    return p.KS == 3 && p.stride == 1 && (p.up == 0 || p.up == 1) && p.pad == 1 && !p.geglu && !p.act && p.Cin % 64 == 0 &&
+           p.Cout % 8 == 0 && halo_patch_width(p.OH, p.OW) > 0 && p.OH == p.H << p.up && p.OW == p.W << p.up &&
+           p.K == 9 * p.Cin;
 }
 
+template <int BN>
 int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
-    const int Wt = halo_patch_width(p.H, p.W), R = 256 / Wt;
-    const size_t lds = (size_t)2 * (R + 2) * (Wt + 2) * 128 + (size_t)3 * 160 * 128;
+    const int Wt = halo_patch_width(p.OH, p.OW), R = 256 / Wt;
+    size_t lds = (size_t)2 * (R + 2) * (Wt + 2) * 128 + (size_t)3 * BN * 128;
+    const size_t epi = (size_t)256 * (BN + 8) * 2 + 16 + 512 * 16;       // staging tile + GroupNorm partials
+    if (lds < epi) lds = epi;
     static size_t attr_by_dev[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& attr = attr_by_dev[dev & 63];
     if (lds > attr) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
-    const int tiles = (p.M / 256) * cdiv(p.Cout, 160);
+    const int tiles = (p.M / 256) * cdiv(p.Cout, BN);
     const int nslab = p.Cin / 64;
     const int per = cdiv(nslab, splits);
     const int eff_splits = cdiv(nslab, per);
     IGemmParams q = p;
     q.mfast = weights_outweigh_activations(p);
-    hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, eff_splits), dim3(512), lds, s, q, eff_splits > 1 ? partial : nullptr,
+    if (eff_splits > 1) q.gnstat_out = nullptr;
+    hipLaunchKernelGGL(conv3x3_halo_kernel<BN>, dim3(tiles, eff_splits), dim3(512), lds, s, q, eff_splits > 1 ? partial : nullptr,
                        per);
     SD_HIP_CHECK(hipGetLastError());
     if (eff_splits > 1) {
@@ -904,7 +936,9 @@ int g_force_splits = 0;
 //   0: 256x128 8 waves 3 stages   1: 128x128 4 waves 2 stages   2: 128x160 4 waves 2 stages
 //   3: 128x64 4 waves 2 stages    4: 64x64 4 waves 2 stages     5: 256x160 4 waves (4x1) 3 stages
 //   6 / 7: 256x128 / 256x160, 8 waves, staggered DMA issue
-//   10: conv3x3_halo_kernel (256x160, A halo tile resident across the taps; 3x3 stride-1 convs, W in 16/32/64)
+//   10 / 15: conv3x3_halo_kernel<160> / <128> (256x160 / 256x128, A halo tile resident across the taps; 3x3 stride-1
+//          convs, W in 16/32/64; the 128-column form for the VAE's 128 / 256 / 512 widths, and it can leave
+//          GroupNorm summaries)
 //   11 / 12: 128x80 (4 x 1 waves, 2- / 3-deep ring): M = 2048, N = 1280 is exactly 256 such tiles -- one per CU at the
 //          least L2 -> LDS traffic a 256-tile grid can have there (133 MB against the 64x64 tile's 205 MB)
 //   13 / 14: wsgemm.hip -- persistent, weight-stationary 128x160 / 128x128 (GEGLU) tiles for the K = 320 pointwise
@@ -924,10 +958,10 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<64,64,2,2,2,%s,false,64>",   "igemm2_kernel<256,160,4,1,3,%s,false,64>",
     "igemm2_kernel<256,128,4,2,3,%s,true,64>",  "igemm2_kernel<256,160,4,2,3,%s,true,64>",
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
-    "conv3x3_halo_kernel",
+    "conv3x3_halo_kernel<160>",
     "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>",
-    "wsgemm_kernel<160,false,...>", "wsgemm_kernel<128,true,...>"};
-constexpr int kNumVariants = 15;
+    "wsgemm_kernel<160,false,...>", "wsgemm_kernel<128,true,...>", "conv3x3_halo_kernel<128>"};
+constexpr int kNumVariants = 16;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -940,7 +974,7 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}, {128, 80}, {128, 128}};
+                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}, {128, 80}, {128, 128}, {256, 128}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -965,7 +999,7 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     igemm2_pick_raw(p, variant, splits);
     if (p.ln_stat) *splits = 1;          // the LayerNorm correction lives in the fused epilogue only
     const bool ws_ok = wsgemm_supported(p);
-    if (*variant >= 13 && !ws_ok) { *variant = p.geglu ? 1 : 2; *splits = 1; }     // (forced on a problem it does not take)
+    if ((*variant == 13 || *variant == 14) && !ws_ok) { *variant = p.geglu ? 1 : 2; *splits = 1; }     // (forced on a problem it does not take)
     // (with a residual the streamed tiles win by 1-6 us per launch -- profiles/r02_wsgemm.txt -- so those stay on them
     // unless variant 13 is forced)
     if (g_force_variant < 0 && ws_ok && !p.res && wsgemm_enabled()) { *variant = p.geglu ? 14 : 13; *splits = 1; }
@@ -980,7 +1014,7 @@ bool igemm2_emits_rowstats(const IGemmParams& p, int* parts) {
     static float sentinel;
     if (!q.rowstat_out) q.rowstat_out = &sentinel;
     igemm2_pick(q, &v, &sp);
-    if (sp > 1 || v == 10) return false;
+    if (sp > 1 || v == 10 || v == 15) return false;
     if (v == 13) { *parts = wsgemm_rowstat_parts(p); return *parts <= kMaxLnParts; }
     int bm, bn;
     tile_dims(v, &bm, &bn);
@@ -997,9 +1031,9 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
     static float sentinel;
     q.gnstat_out = &sentinel;
     igemm2_pick(q, &v, &sp);
-    if (sp > 1 || v >= 13) return false;
-    if (v == 10 && !halo_supported(p)) v = 7;
-    if (v == 10) return false;                          // see conv3x3_halo_kernel
+    if (sp > 1 || v == 13 || v == 14) return false;
+    if ((v == 10 || v == 15) && !halo_supported(p)) v = 7;
+    if (v == 10) return false;                          // see conv3x3_halo_kernel (the 128-column form, 15, can)
     int bm, bn;
     tile_dims(v, &bm, &bn);
     const int OHW = p.OH * p.OW;
@@ -1013,16 +1047,16 @@ static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
     if (g_force_variant >= 0) {
         *variant = g_force_variant;
         *splits = g_force_splits > 0 ? g_force_splits : 1;
-        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6 && *variant < 13) *variant = 1;
+        if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6 && *variant != 13 && *variant != 14) *variant = 1;
         if (p.geglu || p.act) *splits = 1;
-        if (*variant == 10 && !halo_supported(p)) *variant = 7;
+        if ((*variant == 10 || *variant == 15) && !halo_supported(p)) *variant = 7;
         return;
     }
     for (const TunedEntry& e : kTuned)
         if (!p.act && e.M == p.M && e.N == p.Cout && e.K == p.K && e.ks == p.KS && e.stride == p.stride && e.up == p.up &&
             e.geglu == p.geglu) {
             *variant = e.variant; *splits = e.splits;
-            if (*variant == 10 && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
+            if ((*variant == 10 || *variant == 15) && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
             // A GroupNorm reads this output: the halo kernel cannot leave the summaries (register ceiling), so
             // it costs that GroupNorm its own statistics pass (~12 us + 1 us per 4 MB, measured); take the best
             // tile that can, unless the halo kernel leads by more than that.
@@ -1085,7 +1119,8 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 7: return launch_v2<256, 160, 4, 2, 3, true>(p, partial, sp, s);
         case 8: return launch_v2<128, 64, 2, 2, 3>(p, partial, sp, s);
         case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
-        case 10: return launch_halo(p, partial, sp, s);
+        case 10: return launch_halo<160>(p, partial, sp, s);
+        case 15: return launch_halo<128>(p, partial, sp, s);
         case 11: return launch_v2<128, 80, 4, 1, 2>(p, partial, sp, s);
         case 12: return launch_v2<128, 80, 4, 1, 3>(p, partial, sp, s);
         case 13:

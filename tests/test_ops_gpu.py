@@ -72,7 +72,7 @@ def test_conv2d(engine_lib, case):
     assert rel_l2(got, ref) < 2e-3            # fp16 output rounding: ~5e-4 relative
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15])
 @pytest.mark.parametrize("splits", [1, 3])
 def test_conv2d_every_tile_variant(engine_lib, variant, splits):
     """Every LDS-DMA tile variant (and the split-K reduction) on a 3x3, a strided, an upsampled and a
@@ -83,7 +83,9 @@ def test_conv2d_every_tile_variant(engine_lib, variant, splits):
                      (1, 9, 7, 128, 72, 3, 1, 1, True), (2, 17, 5, 256, 200, 1, 1, 0, True),
                      # shapes a 256-pixel patch tiles: the halo kernel (variant 10) takes them, the others run them as ordinary 3x3s
                      (2, 16, 16, 128, 200, 3, 1, 0, True), (1, 8, 32, 64, 320, 3, 1, 0, True), (1, 64, 64, 64, 72, 3, 1, 0, True),
-                     (1, 32, 48, 64, 72, 3, 1, 0, True), (1, 8, 128, 128, 160, 3, 1, 0, True)]:   # 16- and 64-wide patches
+                     (1, 32, 48, 64, 72, 3, 1, 0, True), (1, 8, 128, 128, 160, 3, 1, 0, True),    # 16- and 64-wide patches
+                     # nearest-2x upsample fused into the gather, output images a 256-pixel patch tiles (halo kernels)
+                     (1, 16, 16, 64, 200, 3, 1, 1, True), (2, 8, 32, 128, 160, 3, 1, 1, True), (1, 24, 8, 64, 128, 3, 1, 1, False)]:
             test_conv2d(engine_lib, case)
     finally:
         engine_lib.sd_igemm_force(-1, 0)
