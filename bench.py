@@ -84,8 +84,8 @@ def live_roofline(lib, unet, vae, B, lat_hw, ehs, device, added=None):
 
 
 def _profile_file(stem: str):
-    """Newest committed profile of that kind: profiles/r02_<stem>, else round 1's."""
-    for tag in ("r02", "r01"):
+    """Newest committed profile of that kind: profiles/r03_<stem>, else an earlier round's."""
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{stem}")
         if os.path.exists(path):
             return path
@@ -166,9 +166,15 @@ def roofline_report(urows, vrows):
                            "launches_per_unet_forward": launches,
                            "algorithmic_MB_per_launch": round(nbytes / launches / 1e6, 2),
                            "avg_launch_us": round(ms / launches * 1e3, 2),
+                           "frac_clock": "hip_event_bracket (avg_launch_us, measured live in this run; reads ~10 % "
+                                         "longer than the kernel trace because an event between two launches keeps the "
+                                         "next kernel's ramp from overlapping the previous tail)",
                            "rocprofv3_avg_launch_us": rocprof_avg_us_for(top),
                            "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 3),
                            "scope": "all template instantiations of the function, one UNet forward (CFG batch)"}
+        rp = out["roofline"]["rocprofv3_avg_launch_us"]
+        # the same fraction on the committed rocprofv3 kernel-trace clock (same command, profiles/)
+        out["roofline"]["frac_rocprofv3_clock"] = round(flops / launches / (rp * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) if rp else None
     else:
         ach = nbytes / (ms / 1e3) / 1e9
         out["roofline"] = {"kernel": top, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -188,6 +194,19 @@ def roofline_report(urows, vrows):
     out["kernels_unet_forward"] = fmt(urows)
     out["kernels_vae_decode"] = fmt(vrows)
     return out
+
+
+def box_probe(lib, stream=None):
+    """Fixed, model-independent probe of the box, run in-process BEFORE and outside the timed region
+    (VERDICT r2 item 2): ~40 ms of back-to-back v_mfma_f32_16x16x32_f16 on register operands (dense fp16
+    TFLOP/s the box sustains, random operands) and a 16-byte-per-lane copy of 512 MiB -> 512 MiB (GB/s read +
+    write, beyond the Infinity Cache).  `value / box_probe.mfma_tflops` compares rounds across boxes."""
+    tf, gb = C.c_float(), C.c_float()
+    _lib.check(lib.sd_probe_mfma(300000, C.byref(tf), None), "sd_probe_mfma")
+    _lib.check(lib.sd_probe_copy(512 << 20, 5, C.byref(gb), None), "sd_probe_copy")
+    return {"mfma_tflops": round(tf.value, 1), "hbm_gbs": round(gb.value, 1),
+            "what": "sd_probe_mfma: 300000 x 16 v_mfma_f32_16x16x32_f16 per wave, 4 waves per CU, random operands; "
+                    "sd_probe_copy: 5 x (512 MiB -> 512 MiB) float4 copy, read + write bytes"}
 
 
 def usable_cores() -> int:
@@ -356,6 +375,7 @@ def main():
     model.set_scheduler(args.scheduler)
     pipe = StableDiffusionUnifiedPipeline(do_cfg=True, device=str(device))
 
+    probe = box_probe(lib) if rank == 0 else None
     B = args.batch
     lat_hw = args.res // 8
     total = B * n_gpus
@@ -455,9 +475,11 @@ def main():
                                    f"batch {B}/GPU, CFG on (UNet batch {2 * B}), UNet + VAE decode HIP kernels",
                        "global_batch": total, "parallelism": f"dp{n_gpus}", "guidance_scale": args.guidance},
             "unet_forward_ms": round(unet_ms, 3), "vae_decode_ms": round(vae_ms, 3),
-            "outputs_finite": finite, "unet_hipgraph": bool(args.graph),
+            "outputs_finite": finite, "unet_hipgraph": bool(args.graph), "box_probe": probe,
             "extra": {"latents_4x128x128": large},
         }
+        if probe:
+            result["value_per_probe_pflops"] = round(value / (probe["mfma_tflops"] / 1e3), 4)
         if u_tf and v_tf:
             tflop = args.denoise_steps * 2 * B * u_tf + B * v_tf     # per GPU per pass
             result["whole_path_mfma_frac"] = round(tflop / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4)

@@ -219,6 +219,14 @@ typedef struct sd_prof_entry {
 int sd_prof_enable(int on);
 int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries);
 
+/* Box probe for bench.py (`box_probe`): model-independent microbenchmarks run in-process next to the timed
+ * region so that `value` can be read against the box it ran on (the reference has no counterpart; it serves the
+ * measurement contract only).  sd_probe_mfma: `iters` rounds of 16 back-to-back v_mfma_f32_16x16x32_f16 per wave,
+ * one wave per SIMD on every CU, random operands -> dense fp16 TFLOP/s.  sd_probe_copy: `iters` passes of a
+ * 16-byte-per-lane copy of `bytes` (choose > 256 MiB to pass the Infinity Cache) -> GB/s, read + write. */
+int sd_probe_mfma(int iters, float* tflops, void* stream);
+int sd_probe_copy(int64_t bytes, int iters, float* gbs, void* stream);
+
 /* Tuner / test hook: force the LDS-DMA conv kernel's tile variant (0..5) and split-K factor for
  * every following launch; variant -1 restores the built-in per-shape choice. */
 int sd_igemm_force(int variant, int splits);

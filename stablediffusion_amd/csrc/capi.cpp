@@ -232,6 +232,16 @@ int sd_cfg_ddim_step(const void* noise_pred_2b, void* latents, int64_t n, float 
                            guidance_scale, c_x, c_eps, static_cast<hipStream_t>(stream));
 }
 
+// ------------------------------------------------------------------------------------------- probe
+int sd_probe_mfma(int iters, float* tflops, void* stream) {
+    if (iters < 1 || !tflops) { set_error("sd_probe_mfma: bad arguments"); return SD_ERR_INVALID; }
+    return probe_mfma(iters, tflops, static_cast<hipStream_t>(stream));
+}
+int sd_probe_copy(int64_t bytes, int iters, float* gbs, void* stream) {
+    if (bytes < 4096 || iters < 1 || !gbs) { set_error("sd_probe_copy: bad arguments"); return SD_ERR_INVALID; }
+    return probe_copy((long)bytes, iters, gbs, static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------ tuning
 int sd_igemm_force(int variant, int splits) { igemm2_force(variant, splits); return SD_OK; }
 

@@ -160,4 +160,8 @@ int launch_cfg_linear(const half_t* eps2b, half_t* lat, float* hist, long n, flo
 int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx, float ce,
                     hipStream_t s);
 
+// Box probe (probe.hip): back-to-back 16x16x32 f16 MFMA loop (TFLOP/s) and a 16-byte-per-lane copy (GB/s, read + write)
+int probe_mfma(int iters, float* tflops, hipStream_t s);
+int probe_copy(long bytes, int iters, float* gbs, hipStream_t s);
+
 }  // namespace sd

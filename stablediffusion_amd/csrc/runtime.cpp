@@ -421,7 +421,14 @@ void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G,
     // bytes really moved: the single-kernel form and the apply pass read x and write y; only the
     // stand-alone statistics pass reads x once more
     const bool own_pass = gn_wants_stats(HW, n.C, G) && !st;
-    prof_open(c.stream, own_pass ? "groupnorm(stats+apply)" : "groupnorm(apply)", 0.0, (own_pass ? 6.0 : 4.0) * N * HW * n.C);
+    const char* gname = own_pass ? "groupnorm(stats+apply)" : "groupnorm(apply)";
+    static thread_local char gbuf[64];
+    static const bool gn_by_shape = getenv("SD_PROF_SHAPES") != nullptr;
+    if (gn_by_shape && prof_enabled()) {
+        snprintf(gbuf, sizeof(gbuf), "gn%s %ldx%d%s", own_pass ? "(stats+apply)" : (st ? "(apply)" : "(fused)"), (long)N * HW, n.C, silu ? " silu" : "");
+        gname = gbuf;
+    }
+    prof_open(c.stream, gname, 0.0, (own_pass ? 6.0 : 4.0) * N * HW * n.C);
     c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream, st);
     prof_close(c.stream);
 }
