@@ -254,6 +254,16 @@ int sd_op_conv2d_groupnorm(const void* x_nhwc, const void* w_oihw, const void* b
                            const void* res_nhwc, void* y_conv_nhwc, const void* gamma, const void* beta,
                            void* y_gn_nhwc, int N, int H, int W, int Cin, int Cout, int ksize, int stride,
                            int upsample2x, int groups, float eps, int silu, int* stats_from_epilogue, void* stream);
+/* GroupNorm (+ SiLU) followed by a convolution, the pair ResnetBlock2D issues twice (norm1 -> SiLU -> conv1,
+ * norm2 -> SiLU -> conv2; diffusers resnet.py under sd_unified_pipeline.py:475-482, :523):
+ *   y = conv(act(GroupNorm(x; gamma, beta, groups, eps))) + bias + rowadd + res
+ * For 3x3 / stride-1 convolutions the convolution applies the norm to its input tiles in LDS and the normalised
+ * tensor never exists in HBM (*fused = 1); otherwise a GroupNorm kernel runs first (*fused = 0).  iters > 0: timed
+ * like sd_bench_conv2d (the statistics pass is outside the timed launches), ms_per_launch written. */
+int sd_op_groupnorm_conv2d(const void* x_nhwc, const void* gamma, const void* beta, int groups, float eps, int silu,
+                           const void* w_oihw, const void* bias, const void* rowadd, const void* res_nhwc, void* y_nhwc,
+                           int N, int H, int W, int Cin, int Cout, int ksize, int iters, float* ms_per_launch, int* fused,
+                           void* stream);
 /* Same operator, timed: `iters` back-to-back launches bracketed by HIP events on `stream`
  * (after two warm-up launches); used by tools/tune_igemm.py to pick tile variants per shape. */
 int sd_bench_conv2d(const void* x_nhwc, const void* w_oihw, void* y_nhwc, int N, int H, int W, int Cin,

@@ -284,9 +284,17 @@ struct GnTail {
     const float* gamma; const float* beta; void* y; int groups; float eps; int silu; int* fused;
 };
 
+// Optional GroupNorm (+ SiLU) in FRONT of the convolution (sd_op_groupnorm_conv2d): statistics pass over x, then the
+// convolution applies the norm to its halo tiles in LDS (igemm2_gn_fusable) -- or, when the launch cannot, a GroupNorm
+// kernel runs first; *fused tells which path ran.
+struct GnHead {
+    const float* gamma; const float* beta; int groups; float eps; int silu; int* fused;
+};
+
 static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res,
                        void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int upsample2x,
-                       int geglu, void* stream, int iters, float* ms_out, const GnTail* gn = nullptr) {
+                       int geglu, void* stream, int iters, float* ms_out, const GnTail* gn = nullptr,
+                       const GnHead* gh = nullptr) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long K = (long)ksize * ksize * Cin;
     if (K % 64 != 0 || Cin % 64 != 0) { set_error("sd_op_conv2d: Cin must be a multiple of 64"); return SD_ERR_INVALID; }
@@ -351,6 +359,37 @@ static int conv2d_impl(const void* x, const void* w_oihw, const void* bias_f32, 
                 p.gnstat_out = gnbuf; p.gn_groups = gn->groups;
                 gst.part = gnbuf; gst.rows = rows; gst.S = p.OH * p.OW / rows;
                 if (gn->fused) *gn->fused = 1;
+            }
+        }
+        if (gh) {
+            if (gh->fused) *gh->fused = 0;
+            const long HW = (long)H * W;
+            float* hscratch = nullptr;
+            SD_DEV_ALLOC(scope, hscratch, (size_t)(gn_scratch_floats(N, HW, Cin, gh->groups) + (long)N * gh->groups * 2) * 4);
+            static const bool no_fuse = getenv("SD_NO_GN_FUSE") != nullptr;
+            if (!no_fuse && Cin % 64 == 0 && igemm2_gn_fusable(p, gh->groups)) {
+                // [Cin / 64][64 gamma | 64 beta], as WeightStore::pack_norm leaves it
+                float* gb = nullptr;
+                SD_DEV_ALLOC(scope, gb, (size_t)Cin * 2 * 4);
+                for (int blk = 0; blk < Cin / 64; ++blk) {
+                    SD_HIP_CHECK(hipMemcpyAsync(gb + blk * 128, gh->gamma + blk * 64, 256, hipMemcpyDeviceToDevice, s));
+                    SD_HIP_CHECK(hipMemcpyAsync(gb + blk * 128 + 64, gh->beta + blk * 64, 256, hipMemcpyDeviceToDevice, s));
+                }
+                GnStats st;
+                rc = launch_gn_stats(p.x, p.ldx, N, HW, Cin, gh->groups, hscratch, &st, s);
+                if (!rc && st.S > 64) rc = launch_gn_finalize(&st, hscratch + gn_scratch_floats(N, HW, Cin, gh->groups), N, HW, Cin, gh->groups, s);
+                p.gni_part = st.part; p.gni_S = st.S; p.gni_rows = st.rows; p.gni_groups = gh->groups; p.gni_eps = gh->eps;
+                p.gni_silu = gh->silu; p.gni_gb = gb;
+                if (gh->fused) *gh->fused = 1;
+                if (v2 && !partial) {
+                    const long pf = igemm2_partial_floats(p);
+                    if (pf > 0) SD_DEV_ALLOC(scope, partial, (size_t)pf * sizeof(float));
+                }
+            } else {
+                half_t* hn = nullptr;
+                SD_DEV_ALLOC(scope, hn, (size_t)N * HW * Cin * sizeof(half_t));
+                rc = launch_groupnorm(p.x, p.ldx, gh->gamma, gh->beta, hn, Cin, N, HW, Cin, gh->groups, gh->eps, gh->silu, hscratch, s);
+                p.x = hn;
             }
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -438,6 +477,16 @@ int sd_op_conv2d_groupnorm(const void* x, const void* w_oihw, const void* bias_f
               stats_from_epilogue};
     return conv2d_impl(x, w_oihw, bias_f32, rowadd_f32, res, y_conv, N, H, W, Cin, Cout, ksize, stride, upsample2x, 0,
                        stream, 1, nullptr, &gn);
+}
+
+int sd_op_groupnorm_conv2d(const void* x, const void* gamma_f32, const void* beta_f32, int groups, float eps, int silu,
+                           const void* w_oihw, const void* bias_f32, const void* rowadd_f32, const void* res, void* y, int N,
+                           int H, int W, int Cin, int Cout, int ksize, int iters, float* ms_per_launch, int* fused,
+                           void* stream) {
+    if (!x || !gamma_f32 || !beta_f32 || !w_oihw || !y || groups < 1) { set_error("sd_op_groupnorm_conv2d: bad arguments"); return SD_ERR_INVALID; }
+    GnHead gh{static_cast<const float*>(gamma_f32), static_cast<const float*>(beta_f32), groups, eps, silu, fused};
+    return conv2d_impl(x, w_oihw, bias_f32, rowadd_f32, res, y, N, H, W, Cin, Cout, ksize, 1, 0, 0, stream,
+                       iters > 0 ? iters : 1, iters > 0 ? ms_per_launch : nullptr, nullptr, &gh);
 }
 
 int sd_bench_conv2d(const void* x, const void* w_oihw, void* y, int N, int H, int W, int Cin, int Cout, int ksize,

@@ -71,10 +71,17 @@ struct ConvFuse {
     RowStat* stat_out = nullptr;        // row statistics of the OUTPUT for the LayerNorm that follows
     GnStatBuf* gn_out = nullptr;        // GroupNorm summaries of the OUTPUT for the GroupNorm that follows
     int gn_groups = 0;
+    // GroupNorm (+ SiLU) of the INPUT applied inside the convolution (set by op_gn_conv when igemm2_gn_fusable):
+    const struct NormW* gn_in = nullptr;
+    GnStats gn_in_stats;                // (mean, M2) summaries of the input
+    int gn_in_groups = 0;
+    float gn_in_eps = 0.f;
+    int gn_in_silu = 0;
 };
 struct NormW {
     float* gamma = nullptr;
     float* beta = nullptr;
+    float* gb = nullptr;     // [C / 64][64 gamma | 64 beta]: what the fused GroupNorm's DMA piece reads (C % 64 == 0)
     int C = 0;
 };
 
@@ -149,6 +156,12 @@ inline long rowstat_floats(long M, int C) { return M * ((C + 63) / 64) * 2; }
 inline long gnstat_floats(int N, long HW, int G) { return (long)N * ((HW + 63) / 64) * G * 2; }
 void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu,
                   const GnStatBuf* pre = nullptr);
+// y = conv(act(GroupNorm(x))): inside the convolution when the launch can apply the norm to its halo tiles in LDS
+// (igemm2_gn_fusable; the normalised tensor never exists), otherwise GroupNorm kernel + convolution.  `pre` = the
+// summaries of x its producer left (or nullptr: a statistics pass runs); the other arguments as op_conv's.
+void op_gn_conv(Ctx& c, const NormW& n, const ConvW& w, View x, int N, int H, int W, View y, int G, float eps, int silu,
+                const GnStatBuf* pre, const float* rowadd = nullptr, int rowadd_ld = 0, const View* res = nullptr,
+                const ConvFuse* fuse = nullptr);
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps);
 void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal = 0,
                   int prescaled = 0);

@@ -576,7 +576,22 @@ __host__ __device__ inline int halo_patch_width(int H, int W) {
 // scratch and reloads them inside the main loop: 58.8 -> 72.7 us on the 64x64 320->320 conv, more than the
 // 19 us statistics pass it would save.  (Its 8 spilled dwords stay outside the loop; check
 // `scratch_` against the v_mfma range in the ISA after any change here.)
-template <int BN>
+//
+// GNF: GroupNorm (+ SiLU) of the INPUT fused in (diffusers ResnetBlock2D: norm -> SiLU -> conv, under
+// sd_unified_pipeline.py:475-482 / :523).  The halo tile of a slab is transformed IN LDS, in place, after its DMA has
+// landed and before its first tap reads it: y = silu(x * scale_c + shift_c) with scale_c = rstd_{n,g(c)} gamma_c,
+// shift_c = beta_c - mean_{n,g(c)} scale_c.  Every thread transforms exactly the 16-byte slots it issued itself (so it
+// knows in-image from border: border slots stay zero, the convolution pads the NORMALISED tensor), one slot per tap of
+// the PREVIOUS slab's taps 3..8, i.e. next to that tap's 40 MFMAs; mean / rstd of the block's image are merged from the
+// producer's (mean, M2) summaries in the prologue, the slab's 64 gamma | beta values arrive by one more DMA piece and
+// are turned into scale | shift by wave 0 at tap 2.  The normalised tensor never exists in HBM (a 42 MB round trip and
+// a launch per GroupNorm at the 64 x 64 level).
+// KHU: the three kernel rows unrolled (all nine taps straight-line).  Unrolled, the 72 LDS addresses of the taps are
+// hoisted out of the slab loop: 4-13 % faster, but the 160-column form then sits on the 256-VGPR ceiling (8 dwords
+// spilled outside the loop) and has no room for the GroupNorm summaries in its epilogue; with the rows as a loop it
+// needs ~190 registers and leaves them (62 us with summaries against 55 us without and 69 us for the best streaming tile
+// that can, 64 x 64 level 320 -> 320).  So: unrolled unless the launch has to leave summaries at 160 columns.
+template <int BN, bool GNF, bool KHU>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float* partial, int slabs_per_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(BN == 160 || BN == 128, "column tile");
@@ -586,6 +601,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     constexpr int B_INSTR = BN / 8, B_PW = (B_INSTR + NW - 1) / NW, B_REM = B_INSTR % NW;   // 160: 20 = 4 waves x 3 + 4 x 2; 128: 2 each
     constexpr int B_STAGE_HALVES = BN * 64;     // three ring stages: one per tap of a kernel row
     constexpr int AJ = 7;                        // halo DMA instructions per wave, at most
+    constexpr int KH_UNROLL = KHU ? 3 : 1;
     constexpr int LDC = BN + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // tile = an R x Wt patch of one image (Wt = the widest of 64 / 32 / 16 that divides W, R = 256 / Wt)
@@ -600,6 +616,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     half_t* sA = reinterpret_cast<half_t*>(smem);            // [2][HP][64], swizzled on the pixel index
     half_t* sB = sA + 2 * A_HALVES;                          // [3][160][64]
     half_t* sC = reinterpret_cast<half_t*>(smem);            // epilogue staging overlays both
+    float* sCoef = reinterpret_cast<float*>(sB + 3 * B_STAGE_HALVES);   // GNF: [64 scale | 64 shift] of the slab in preparation
+    float* sGS = sCoef + 128;                                // GNF: [groups][mean, rstd] of the block's image
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -659,6 +677,46 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
             }
         }
     };
+    // ---- GNF: the slab's [64 gamma | 64 beta] (NormW::gb, packed per 64 channels) -> sCoef by one DMA piece of wave 0;
+    //      wave 0 then turns them into scale | shift in place; a slot is normalised through them ----
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GNF ? p.gni_gb : nullptr), 0,
+                                                                  GNF ? p.Cin * 8 : 0, 0x00020000);
+    auto issueCoef = [&](int slab) {
+        if (wave == 0 && lane < 32)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)sCoef, 16,
+                                                     (unsigned)(slab * 512 + lane * 16), 0, 0, 0);
+    };
+    const float gni_inv_cpg = GNF ? 1.0f / (float)(p.Cin / p.gni_groups) : 0.f;
+    auto convertCoef = [&](int slab) {               // wave 0, after its own wait for the piece
+        if (wave == 0) {
+            const int g = (int)(((float)(slab * 64 + lane) + 0.5f) * gni_inv_cpg);
+            const float gam = sCoef[lane], bet = sCoef[64 + lane];
+            const float sc = sGS[g * 2 + 1] * gam;
+            sCoef[lane] = sc;
+            sCoef[64 + lane] = bet - sGS[g * 2] * sc;
+        }
+    };
+    const int chunkA = (lane & 7) ^ (lane >> 3);    // the 8-channel chunk of every halo slot this thread owns
+    auto gnSlot = [&](int bufi, int j) {
+        const int i = wave + NW * j;
+        if (i < NI && a_off[j] >= 0) {               // in-image slot (border slots stay zero; -1: no slot)
+            half_t* ptr = sA + bufi * A_HALVES + i * 512 + lane * 8;
+            const h8 xv = *reinterpret_cast<const h8*>(ptr);
+            const float* cs = sCoef + chunkA * 8;
+            const f4 c0 = *reinterpret_cast<const f4*>(cs), c1 = *reinterpret_cast<const f4*>(cs + 4);
+            const f4 d0 = *reinterpret_cast<const f4*>(cs + 64), d1 = *reinterpret_cast<const f4*>(cs + 68);
+            h8 yv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = (float)xv[e] * c0[e] + d0[e];
+                float b = (float)xv[e + 4] * c1[e] + d1[e];
+                if (p.gni_silu) { a = silu_f(a); b = silu_f(b); }
+                yv[e] = (half_t)a;
+                yv[e + 4] = (half_t)b;
+            }
+            *reinterpret_cast<h8*>(ptr) = yv;
+        }
+    };
     // ---- weight tile: 8 rows of 64 halves per DMA instruction, chunk ^ (row & 7) on the source side ----
     const int lrow = lane >> 3;
     const int chunkB = (lane & 7) ^ lrow;
@@ -696,9 +754,53 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     int g = s_begin * 9;
     const int g_end = s_end * 9;
     if (g < g_end) {
+        if constexpr (GNF) issueCoef(s_begin);
         issueA(0, s_begin);
         issueB(0, g);
         if (g + 1 < g_end) issueB(1, g + 1);
+    }
+    if constexpr (GNF) {
+        // mean / rstd of the block's image from the producer's (mean, M2) summaries (Chan merges in a fixed order):
+        // 512 / G threads per group take interleaved summaries, thread g merges those.  Scratch: halo buffer 1.
+        float* red = reinterpret_cast<float*>(sA + A_HALVES);
+        const int G = p.gni_groups, parts = NT / G;
+        const float cpgf = (float)(p.Cin / G);
+        {
+            const int gi = tid % G, pi = tid / G;
+            if (pi < parts) {
+                float nA = 0.f, mA = 0.f, qA = 0.f;
+                const float* src = p.gni_part + ((long)img * p.gni_S * G + gi) * 2;
+                for (int k = pi; k < p.gni_S; k += parts) {
+                    long rows = (long)IHW - (long)k * p.gni_rows;
+                    if (rows > p.gni_rows) rows = p.gni_rows;
+                    const float nB = (float)rows * cpgf, mB = src[(long)k * G * 2], qB = src[(long)k * G * 2 + 1];
+                    const float n = nA + nB, d = mB - mA, f = nB / n;
+                    mA += d * f; qA += qB + d * d * nA * f; nA = n;
+                }
+                red[(pi * G + gi) * 3] = nA; red[(pi * G + gi) * 3 + 1] = mA; red[(pi * G + gi) * 3 + 2] = qA;
+            }
+        }
+        __syncthreads();                         // (also waits for the prologue DMA pieces: LDS writes in flight)
+        if (tid < G) {
+            float nA = red[tid * 3], mA = red[tid * 3 + 1], qA = red[tid * 3 + 2];
+            for (int k = 1; k < parts; ++k) {
+                const float nB = red[(k * G + tid) * 3], mB = red[(k * G + tid) * 3 + 1], qB = red[(k * G + tid) * 3 + 2];
+                if (nB > 0.f) {
+                    const float n = nA + nB, d = mB - mA, f = nB / n;
+                    mA += d * f; qA += qB + d * d * nA * f; nA = n;
+                }
+            }
+            const float var = qA / ((float)IHW * cpgf);
+            sGS[tid * 2] = mA;
+            sGS[tid * 2 + 1] = rsqrtf((var < 0.f ? 0.f : var) + p.gni_eps);
+        }
+        __syncthreads();
+        if (g < g_end) {
+            convertCoef(s_begin);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) gnSlot(0, j);
+        }
     }
     // Main loop: slab -> kernel row -> the three taps of the row, unrolled.  The weight ring has three
     // stages, so the stage of a tap is its kw: compile-time, like the waits' immediates (the smallest
@@ -708,6 +810,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     for (int slab = s_begin; slab < s_end; ++slab) {
         const bool lastslab = slab + 1 >= s_end;
         const half_t* cA = sA + abuf * A_HALVES;
+#pragma unroll KH_UNROLL
         for (int kh = 0; kh < 3; ++kh) {
             const bool lastrow = lastslab && kh == 2;
             const int rowoff = kh * Wp;
@@ -718,11 +821,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
                 if (lastrow && kw == 2) wait_vmcnt<0>();
                 else if (a_next && kh == 0 && kw >= 1) wait_vmcnt<7>();
                 else wait_vmcnt<2>();
+                // (GNF: this wave's in-place writes -- halo slots, scale | shift -- are done before it meets the barrier)
+                if constexpr (GNF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (!(lastrow && kw >= 1)) issueB((kw + 2) % 3, g + 2);
                 if (kw == 0 && kh == 0) {
                     a_next = !lastslab;
-                    if (a_next) issueA(abuf ^ 1, slab + 1);
+                    if (a_next) {
+                        if constexpr (GNF) issueCoef(slab + 1);       // older than the halo pieces: landed by tap 2's wait
+                        issueA(abuf ^ 1, slab + 1);
+                    }
                 }
                 const half_t* cB = sB + kw * B_STAGE_HALVES;
                 const int tapoff = rowoff + kw;
@@ -745,6 +853,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
+                if constexpr (GNF) {
+                    // The NEXT slab's halo is normalised during this slab's taps 3..8, one slot per tap (two in the last),
+                    // after the tap's MFMAs: its DMA pieces have landed by tap 3's wait, scale | shift were written by
+                    // wave 0 at tap 2 and published by tap 3's barrier.
+                    // Measured (profiles/r03_gn_fused_conv.txt): the ~100 vector instructions per slot do NOT hide behind
+                    // the MFMAs -- every wave of the block runs them at the same point of the tap, the matrix pipe idles
+                    // meanwhile (+25-30 % per launch); running them first in one wave of each SIMD pair (+50 %) and a
+                    // branch-free form for the scheduler to interleave (spills at full unroll) were worse.
+                    if (a_next) {
+                        const int T = kh * 3 + kw;
+                        if (T == 2) convertCoef(slab + 1);
+                        if (T >= 3) gnSlot(abuf ^ 1, T - 3);
+                        if (T == 8) gnSlot(abuf ^ 1, 6);
+                    }
                 }
             }
         }
@@ -814,7 +937,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
     // GroupNorm summaries of the stored tile (as igemm2_kernel's epilogue) -- in the 128-column form only: with 64
     // accumulator registers instead of 80 the allocator keeps the main loop free of spill reloads (the header
     // comment has what happened at 160 columns)
-    constexpr bool GN = BN == 128;
+    constexpr bool GN = BN == 128 || !KHU;
     const int cpg = (GN && p.gnstat_out) ? p.Cout / p.gn_groups : 8;
     const int g_first = n / cpg;
     const int gsplit = (g_first + 1) * cpg - n;
@@ -854,18 +977,20 @@ bool halo_supported(const IGemmParams& p) {
            p.K == 9 * p.Cin;
 }
 
-template <int BN>
-int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
+template <int BN, bool GNF, bool KHU>
+int launch_halo_t(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     const int Wt = halo_patch_width(p.OH, p.OW), R = 256 / Wt;
-    size_t lds = (size_t)2 * (R + 2) * (Wt + 2) * 128 + (size_t)3 * BN * 128;
+    // [2 halo tiles | 3 weight stages | GNF: 128 floats scale / shift + 64 floats mean / rstd]
+    size_t lds = (size_t)2 * (R + 2) * (Wt + 2) * 128 + (size_t)3 * BN * 128 + (GNF ? 768 : 0);
     const size_t epi = (size_t)256 * (BN + 8) * 2 + 16 + 512 * 16;       // staging tile + GroupNorm partials
     if (lds < epi) lds = epi;
+    if (lds > 160 * 1024) { set_error("conv3x3_halo_kernel: LDS budget"); return 1; }
     static size_t attr_by_dev[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     size_t& attr = attr_by_dev[dev & 63];
     if (lds > attr) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN>),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, GNF, KHU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
@@ -876,7 +1001,7 @@ int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s)
     IGemmParams q = p;
     q.mfast = weights_outweigh_activations(p);
     if (eff_splits > 1) q.gnstat_out = nullptr;
-    hipLaunchKernelGGL(conv3x3_halo_kernel<BN>, dim3(tiles, eff_splits), dim3(512), lds, s, q, eff_splits > 1 ? partial : nullptr,
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, GNF, KHU>), dim3(tiles, eff_splits), dim3(512), lds, s, q, eff_splits > 1 ? partial : nullptr,
                        per);
     SD_HIP_CHECK(hipGetLastError());
     if (eff_splits > 1) {
@@ -887,6 +1012,21 @@ int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s)
         SD_HIP_CHECK(hipGetLastError());
     }
     return 0;
+}
+
+template <int BN>
+int launch_halo(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
+    if (p.gni_part) {
+        if (p.gni_groups < 1 || p.gni_groups > 32 || 512 % p.gni_groups != 0 || p.Cin % p.gni_groups != 0 || !p.gni_gb) {
+            set_error("conv3x3_halo_kernel: fused GroupNorm needs 1..32 groups dividing 512 and the packed affine");
+            return 1;
+        }
+        return launch_halo_t<BN, true, false>(p, partial, splits, s);
+    }
+    if constexpr (BN == 160) {
+        if (p.gnstat_out && splits <= 1) return launch_halo_t<BN, false, false>(p, partial, splits, s);
+    }
+    return launch_halo_t<BN, false, true>(p, partial, splits, s);
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool PW, bool STAG, int BKT>
@@ -995,8 +1135,23 @@ static bool wsgemm_enabled() {
     return !off;
 }
 
+bool igemm2_gn_fusable(const IGemmParams& p, int groups) {
+    return igemm2_supported(p) && halo_supported(p) && p.up == 0 && groups >= 1 && groups <= 32 && 512 % groups == 0 &&
+           p.Cin % groups == 0;
+}
+
 void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     igemm2_pick_raw(p, variant, splits);
+    if (p.gni_part && *variant != 10 && *variant != 15) {
+        // a GroupNorm is applied to the input inside the kernel: only the halo kernel does that.  160 columns where they
+        // divide the width, split over the slabs until about one block per CU is in flight (>= 4 slabs per slice)
+        *variant = p.Cout % 160 == 0 ? 10 : 15;
+        const long tiles = (long)(p.M / 256) * cdiv(p.Cout, *variant == 10 ? 160 : 128);
+        int sp = 1;
+        const int nslab = p.Cin / 64;
+        while (tiles * sp < 192 && nslab / (sp + 1) >= 4 && sp < 8) ++sp;
+        *splits = sp;
+    }
     if (p.ln_stat) *splits = 1;          // the LayerNorm correction lives in the fused epilogue only
     const bool ws_ok = wsgemm_supported(p);
     if ((*variant == 13 || *variant == 14) && !ws_ok) { *variant = p.geglu ? 1 : 2; *splits = 1; }     // (forced on a problem it does not take)
@@ -1033,7 +1188,6 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
     igemm2_pick(q, &v, &sp);
     if (sp > 1 || v == 13 || v == 14) return false;
     if ((v == 10 || v == 15) && !halo_supported(p)) v = 7;
-    if (v == 10) return false;                          // see conv3x3_halo_kernel (the 128-column form, 15, can)
     int bm, bn;
     tile_dims(v, &bm, &bn);
     const int OHW = p.OH * p.OW;
@@ -1057,13 +1211,6 @@ static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
             e.geglu == p.geglu) {
             *variant = e.variant; *splits = e.splits;
             if ((*variant == 10 || *variant == 15) && !halo_supported(p)) *variant = 7;   // (same M x N x K from another image shape)
-            // A GroupNorm reads this output: the halo kernel cannot leave the summaries (register ceiling), so
-            // it costs that GroupNorm its own statistics pass (~12 us + 1 us per 4 MB, measured); take the best
-            // tile that can, unless the halo kernel leads by more than that.
-            if (p.gnstat_out && *variant == 10 && e.alt_variant >= 0 &&
-                e.alt_us - e.us < 12.0f + (float)p.M * (float)p.Cout * 2.0f / 4.0e6f) {
-                *variant = e.alt_variant; *splits = 1;
-            }
             return;
         }
     const int nk = p.K / BK;

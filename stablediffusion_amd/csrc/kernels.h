@@ -50,7 +50,20 @@ struct IGemmParams {
     // x the group's channels (the GnStats layout of launch_groupnorm)
     float* gnstat_out = nullptr;
     int gn_groups = 0;
+    // ---- GroupNorm (+ SiLU) of the INPUT, applied inside the convolution (conv3x3_halo_kernel<BN, true>: the halo
+    //      tile of every 64-channel slab is normalised in LDS after its DMA has landed; igemm2_gn_fusable) ----
+    // gni_part: (mean, M2) summaries of x in the GnStats layout, gni_S of them per image over gni_rows pixels each;
+    // gni_gb: the norm's affine packed per 64 channels [Cin / 64][64 gamma | 64 beta] (NormW::gb).
+    const float* gni_part = nullptr;
+    int gni_S = 0;
+    long gni_rows = 0;
+    int gni_groups = 0;
+    float gni_eps = 0.f;
+    int gni_silu = 0;
+    const float* gni_gb = nullptr;
 };
+// Whether launch_igemm2 can apply a GroupNorm of `groups` groups to this problem's input (p.gni_* set by the caller).
+bool igemm2_gn_fusable(const IGemmParams& p, int groups);
 // Whether launch_igemm2 will honour p.gnstat_out for `groups` groups; *rows = pixels per tile (GnStats::rows).
 bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows);
 // Whether launch_igemm2 will honour p.rowstat_out for this problem (LDS-DMA kernel, no split-K); when not,
@@ -91,6 +104,10 @@ bool gn_wants_stats(long HW, int C, int G);
 int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float* beta,
                      half_t* y, long ldy, int N, long HW, int C, int G, float eps, int silu,
                      float* scratch, hipStream_t s, const GnStats* pre = nullptr);
+// Statistics pass alone: (mean, M2) summaries of x into `scratch` (gn_scratch_floats), described by *st.
+int launch_gn_stats(const half_t* x, long ldx, int N, long HW, int C, int G, float* scratch, GnStats* st, hipStream_t s);
+// Merges the st.S summaries per image into one (into `out`, N * G * 2 floats) and rewrites *st to describe that.
+int launch_gn_finalize(GnStats* st, float* out, int N, long HW, int C, int G, hipStream_t s);
 int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta,
                      half_t* y, long ldy, long rows, int C, float eps, hipStream_t s);
 // stat[m * 2 + {0,1}] = sum, sum of squares of row m (the one-part form of IGemmParams::rowstat_out)

@@ -523,6 +523,23 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
     return 0;
 }
 
+int launch_gn_stats(const half_t* x, long ldx, int N, long HW, int C, int G, float* scratch, GnStats* st, hipStream_t s) {
+    if (C % 8 != 0 || C % G != 0 || G > 256) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
+    const int S = gn_slabs(N, HW, C, G);
+    const int CB = gn_block_channels(C, G);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
+    SD_HIP_CHECK(hipGetLastError());
+    st->part = scratch; st->S = S; st->rows = (HW + S - 1) / S;
+    return 0;
+}
+
+int launch_gn_finalize(GnStats* st, float* out, int N, long HW, int C, int G, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, s, st->part, out, st->S, G, st->rows, HW, C / G);
+    SD_HIP_CHECK(hipGetLastError());
+    st->part = out; st->S = 1; st->rows = HW;
+    return 0;
+}
+
 int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y,
                      long ldy, long rows, int C, float eps, hipStream_t s) {
     if (C % 8 != 0 || C > 64 * 8 * LN_MAX) { set_error("layernorm: unsupported C"); return 1; }

@@ -241,6 +241,18 @@ int WeightStore::pack_norm(const std::string& prefix, NormW* out) {
     if (!out->gamma || !out->beta) { set_error("hipMalloc failed (norm)"); return 3; }
     SD_HIP_CHECK(hipMemcpy(out->gamma, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
     SD_HIP_CHECK(hipMemcpy(out->beta, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+    out->gb = nullptr;
+    if (g.size() % 64 == 0) {          // packed per 64 channels for the convolution-fused GroupNorm
+        std::vector<float> gb(2 * g.size());
+        for (size_t blk = 0; blk < g.size() / 64; ++blk)
+            for (int e = 0; e < 64; ++e) {
+                gb[blk * 128 + e] = g[blk * 64 + e];
+                gb[blk * 128 + 64 + e] = b[blk * 64 + e];
+            }
+        out->gb = static_cast<float*>(dmalloc(gb.size() * sizeof(float)));
+        if (!out->gb) { set_error("hipMalloc failed (norm)"); return 3; }
+        SD_HIP_CHECK(hipMemcpy(out->gb, gb.data(), gb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -351,6 +363,12 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
         if (!w.wsum) { set_error("op_conv: LayerNorm statistics passed to a linear without folded weights"); c.err = 1; return; }
         p.ln_stat = ln_in->p; p.ln_parts = ln_in->parts; p.ln_C = (int)w.K; p.ln_eps = ln_eps; p.ln_wsum = w.wsum;
     }
+    if (fuse && fuse->gn_in) {
+        p.gni_part = fuse->gn_in_stats.part; p.gni_S = fuse->gn_in_stats.S; p.gni_rows = fuse->gn_in_stats.rows;
+        p.gni_groups = fuse->gn_in_groups; p.gni_eps = fuse->gn_in_eps; p.gni_silu = fuse->gn_in_silu;
+        p.gni_gb = fuse->gn_in->gb;
+        if (c.dry) p.gni_part = reinterpret_cast<const float*>(8);      // planning pass: only "is set" matters (tile choice)
+    }
     const bool v2 = igemm2_supported(p);
     if (ln_in && !v2) { set_error("op_conv: the LayerNorm fold needs the LDS-DMA kernel"); c.err = 1; return; }
     if (gn_out) {
@@ -396,8 +414,9 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
             // fused extras) instead of one per kernel instantiation
             static const bool by_shape = getenv("SD_PROF_SHAPES") != nullptr;
             if (by_shape)
-                snprintf(nbuf, sizeof(nbuf), "v%d/k%d %dx%dx%d ks%d%s%s%s%s%s", var, sp, p.M, p.Cout, p.K, p.KS, res ? " res" : "",
-                         geglu ? " geglu" : "", p.ln_stat ? " ln" : "", p.rowstat_out ? " rs" : "", p.gnstat_out ? " gs" : "");
+                snprintf(nbuf, sizeof(nbuf), "v%d/k%d %dx%dx%d ks%d%s%s%s%s%s%s", var, sp, p.M, p.Cout, p.K, p.KS, res ? " res" : "",
+                         geglu ? " geglu" : "", p.ln_stat ? " ln" : "", p.rowstat_out ? " rs" : "", p.gnstat_out ? " gs" : "",
+                         p.gni_part ? " gn" : "");
             name = nbuf;
         }
         prof_open(c.stream, name, 2.0 * p.M * w.cout * kreal,
@@ -431,6 +450,52 @@ void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G,
     prof_open(c.stream, gname, 0.0, (own_pass ? 6.0 : 4.0) * N * HW * n.C);
     c.err = launch_groupnorm(x.p, x.ld, n.gamma, n.beta, y.p, y.ld, N, HW, n.C, G, eps, silu, scratch, c.stream, st);
     prof_close(c.stream);
+}
+
+void op_gn_conv(Ctx& c, const NormW& n, const ConvW& w, View x, int N, int H, int W, View y, int G, float eps, int silu,
+                const GnStatBuf* pre, const float* rowadd, int rowadd_ld, const View* res, const ConvFuse* fuse) {
+    // Off unless SD_GN_FUSE=1: measured slower than GroupNorm kernel + convolution on every UNet shape (the in-LDS
+    // transform does not hide behind the MFMAs, profiles/r03_gn_fused_conv.txt); the kernel stays for the operator
+    // test (sd_op_groupnorm_conv2d) and as the base of the next attempt.
+    static const bool off = getenv("SD_GN_FUSE") == nullptr || getenv("SD_NO_GN_FUSE") != nullptr;
+    const long HW = (long)H * W;
+    // the problem as op_conv will pose it (stride 1, no upsample: the only form that follows a GroupNorm)
+    IGemmParams q;
+    q.x = x.p; q.ldx = x.ld; q.N = N; q.H = H; q.W = W; q.Cin = (w.ks == 1) ? (int)w.K : w.cin;
+    q.KS = w.ks; q.stride = 1; q.up = 0; q.pad = w.ks == 3 ? 1 : 0; q.OH = H; q.OW = W; q.Cout = w.cout;
+    q.M = N * H * W; q.K = (int)w.K;
+    const bool fused = !off && n.gb && n.C == q.Cin && igemm2_gn_fusable(q, G);
+    if (!fused) {
+        const size_t mk = c.arena->mark();
+        View hn(c.arena->alloc_h((long)N * HW * n.C), n.C, n.C);
+        op_groupnorm(c, n, x, hn, N, HW, G, eps, silu, pre);
+        op_conv(c, w, hn, N, H, W, y, 1, 0, rowadd, rowadd_ld, res, 0, -1, 0, fuse);
+        c.arena->release(mk);
+        return;
+    }
+    const size_t mk = c.arena->mark();
+    ConvFuse f = fuse ? *fuse : ConvFuse();
+    f.gn_in = &n; f.gn_in_groups = G; f.gn_in_eps = eps; f.gn_in_silu = silu;
+    float* scratch = c.arena->alloc_f(gn_scratch_floats(N, HW, n.C, G) + (long)N * G * 2);
+    if (pre && pre->st.part) {
+        f.gn_in_stats = pre->st;
+        // many summaries per image (the VAE's 512 x 512 maps): merged once by a small kernel, not by every block's prologue
+        if (f.gn_in_stats.S > 64 && !c.dry && !c.err) {
+            prof_open(c.stream, "gn_finalize_kernel", 0.0, 8.0 * N * f.gn_in_stats.S * G);
+            c.err = launch_gn_finalize(&f.gn_in_stats, scratch, N, HW, n.C, G, c.stream);
+            prof_close(c.stream);
+        }
+    } else if (!c.dry && !c.err) {
+        static thread_local char gbuf[64];
+        static const bool by_shape = getenv("SD_PROF_SHAPES") != nullptr;
+        const char* name = "groupnorm(stats)";
+        if (by_shape && prof_enabled()) { snprintf(gbuf, sizeof(gbuf), "gn(stats) %ldx%d", (long)N * HW, n.C); name = gbuf; }
+        prof_open(c.stream, name, 0.0, 2.0 * N * HW * n.C);
+        c.err = launch_gn_stats(x.p, x.ld, N, HW, n.C, G, scratch, &f.gn_in_stats, c.stream);
+        prof_close(c.stream);
+    }
+    op_conv(c, w, x, N, H, W, y, 1, 0, rowadd, rowadd_ld, res, 0, -1, 0, &f);
+    c.arena->release(mk);
 }
 
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps) {

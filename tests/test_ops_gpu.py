@@ -425,3 +425,60 @@ def test_small_linear(engine_lib, B, K, n_out, silu_in, silu_out):
     assert rc == 0, engine_lib.sd_last_error()
     torch.cuda.synchronize()
     assert rel_l2(y, ref) < 1e-4
+
+
+GN_CONV_CASES = [
+    # N, H, W, Cin, Cout, groups, silu, extras, x_scale, x_shift
+    (2, 16, 16, 64, 64, 32, 1, True, 1.0, 0.0),        # one slab, 16 x 16 patch
+    (2, 32, 32, 128, 320, 32, 1, True, 1.0, 0.0),      # two slabs, 32-wide patch, Cout = 2 x 160
+    (1, 64, 64, 320, 320, 32, 1, True, 2.0, 0.5),      # SD1.5 level 0: five slabs, 64-wide patch, cpg = 10
+    (2, 16, 16, 640, 128, 32, 1, False, 1.0, 0.0),     # ten slabs, cpg = 20, split over the slabs (few tiles)
+    (3, 16, 32, 192, 256, 32, 0, True, 1.0, -1.0),     # no SiLU, cpg = 6 (chunks straddle groups), 128-column form
+    (1, 32, 32, 960, 320, 32, 1, True, 1.0, 0.0),      # concat width of the up path: cpg = 30
+    (1, 32, 32, 128, 128, 32, 1, False, 0.1, 50.0),    # |mean| >> std: the affine runs in fp32
+    (2, 8, 8, 128, 128, 32, 1, True, 1.0, 0.0),        # 8 x 8 maps: no halo patch -> GroupNorm kernel + conv (fused = 0)
+]
+
+
+@pytest.mark.parametrize("case", GN_CONV_CASES)
+def test_groupnorm_conv2d(engine_lib, case):
+    """GroupNorm -> SiLU -> 3x3 conv with the norm applied inside the convolution (conv3x3_halo_kernel<BN, true>:
+    halo tiles normalised in LDS; borders must stay zero = the conv pads the NORMALISED tensor) against
+    F.group_norm -> F.silu -> F.conv2d in fp32."""
+    N, H, W, Cin, Cout, G, silu, extras, xs, xsh = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:6]) + 5)
+    x = (torch.randn(N, Cin, H, W, generator=g) * xs + xsh + 0.3 * torch.randn(1, Cin, 1, 1, generator=g)).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).half()
+    gamma = 1.0 + 0.3 * torch.randn(Cin, generator=g)
+    beta = 0.3 * torch.randn(Cin, generator=g)
+    bias = torch.randn(Cout, generator=g) * 0.5 if extras else None
+    rowadd = torch.randn(N, Cout, generator=g) * 0.5 if extras else None
+    hn = F.group_norm(x.float(), G, gamma, beta, 1e-5)
+    if silu:
+        hn = F.silu(hn)
+    ref = F.conv2d(hn, w.float(), bias, padding=1)
+    if rowadd is not None:
+        ref = ref + rowadd[:, :, None, None]
+    res = torch.randn(ref.shape, generator=g).half() if extras else None
+    if res is not None:
+        ref = ref.half().float() + res.float()
+    y = torch.empty(N, H, W, Cout, dtype=torch.float16, device="cuda")
+    xd = h(x.permute(0, 2, 3, 1))
+    wd = h(w)
+    bd = bias.cuda() if bias is not None else None
+    rd = rowadd.cuda().contiguous() if rowadd is not None else None
+    resd = h(res.permute(0, 2, 3, 1)) if res is not None else None
+    gd, btd = gamma.cuda(), beta.cuda()
+    fused = C.c_int(-1)
+    rc = engine_lib.sd_op_groupnorm_conv2d(P(xd), P(gd), P(btd), G, 1e-5, silu, P(wd), P(bd), P(rd), P(resd), P(y), N, H, W,
+                                           Cin, Cout, 3, 0, None, C.byref(fused), stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert fused.value == (0 if H == 8 else 1)
+    out = y.float().cpu().permute(0, 3, 1, 2)
+    # the normalised activations are rounded to fp16 once (as the separate kernel did): conv-level tolerance
+    assert rel_l2(out, ref) < 3e-3, rel_l2(out, ref)
+    # borders: the outermost output ring sees the zero padding of the normalised tensor
+    ring = torch.ones(H, W, dtype=torch.bool)
+    ring[1:-1, 1:-1] = False
+    assert rel_l2(out[:, :, ring], ref[:, :, ring]) < 4e-3
