@@ -153,7 +153,8 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
 // floats a RowStat buffer needs for an [M, C] tensor whatever tile the producer picks
 inline long rowstat_floats(long M, int C) { return M * ((C + 63) / 64) * 2; }
 // floats a GnStatBuf needs for N images of HW pixels (tiles of >= 64 pixels) and G groups
-inline long gnstat_floats(int N, long HW, int G) { return (long)N * ((HW + 63) / 64) * G * 2; }
+// (a split-K reduction kernel leaves up to 64 summaries per image whatever the map size)
+inline long gnstat_floats(int N, long HW, int G) { const long t = (HW + 63) / 64; return (long)N * (t > 64 ? t : 64) * G * 2; }
 void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G, float eps, int silu,
                   const GnStatBuf* pre = nullptr);
 // y = conv(act(GroupNorm(x))): inside the convolution when the launch can apply the norm to its halo tiles in LDS

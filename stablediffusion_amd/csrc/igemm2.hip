@@ -548,6 +548,116 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, con
     }
 }
 
+// The same reduction for an output a GroupNorm reads next, leaving that GroupNorm's summaries (IGemmParams::gnstat_out):
+// one block = RB consecutive pixels of one image x a block of CB columns (whole groups, whole 16-byte chunks); every
+// item (pixel, chunk) hands the sums / sums of squares of its stored fp16 values to LDS, split over the (at most two)
+// groups the chunk touches, and one thread per group adds them in a fixed order: (mean, M2) of [RB pixels x the
+// group's channels], the GnStats layout with rows = RB.  Split-K launches are the small maps (8 x 8 ... 32 x 32):
+// without this their GroupNorm re-read the tensor for its own statistics.  RB = 4 / 16 by map size (at most 64
+// summaries per image), CB <= 320: 512 blocks on the 8 x 8 level's 512 x 1280 outputs.
+__global__ __launch_bounds__(256) void splitk_epilogue_gs_kernel(IGemmParams p, const float* __restrict__ partial, int splits,
+                                                                 int RB, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sI = reinterpret_cast<float*>(smem);                // [RB][CH][4]
+    const int c0 = blockIdx.y * CB;
+    const int cw = p.Cout - c0 < CB ? p.Cout - c0 : CB;
+    const int CH = cw / 8;
+    const long slab = (long)p.M * p.Cout;
+    const int OHW = p.OH * p.OW;
+    const long m0 = (long)blockIdx.x * RB;
+    const int cpg = p.Cout / p.gn_groups;
+    for (int idx = threadIdx.x; idx < RB * CH; idx += 256) {
+        const int r = idx / CH, c8 = idx - r * CH;
+        const long m = m0 + r;
+        const int n = c0 + c8 * 8;
+        float v[8];
+        const float* src = partial + m * p.Cout + n;
+        const f4 a0 = *reinterpret_cast<const f4*>(src), a1 = *reinterpret_cast<const f4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a0[e]; v[e + 4] = a1[e]; }
+        for (int s = 1; s < splits; ++s) {
+            const f4 b0 = *reinterpret_cast<const f4*>(src + s * slab), b1 = *reinterpret_cast<const f4*>(src + s * slab + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+        }
+        if (p.rowadd) {
+            const float* ra = p.rowadd + (m / OHW) * p.rowadd_ld + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += ra[e];
+        }
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+        if (p.res) {
+            const h8 rv = *reinterpret_cast<const h8*>(p.res + m * p.ldres + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)o[e] + (float)rv[e]);
+        }
+        *reinterpret_cast<h8*>(p.y + m * p.ldy + n) = o;
+        const int gsplit = (n / cpg + 1) * cpg - n;          // channels e < gsplit belong to the chunk's first group
+        float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)o[e];
+            if (e < gsplit) { gs0 += f; gq0 += f * f; } else { gs1 += f; gq1 += f * f; }
+        }
+        *reinterpret_cast<f4*>(sI + (long)idx * 4) = f4{gs0, gq0, gs1, gq1};
+    }
+    __syncthreads();
+    const int gl = threadIdx.x;                              // group inside the column block
+    if (gl < cw / cpg) {
+        const int cfirst = (gl * cpg) / 8, clast = ((gl + 1) * cpg - 1) / 8;
+        float sm = 0.f, sq = 0.f;
+        for (int c8 = cfirst; c8 <= clast; ++c8) {
+            const int off = ((c8 * 8) / cpg == gl) ? 0 : 2;
+            for (int r = 0; r < RB; ++r) {
+                const float2 v = *reinterpret_cast<const float2*>(sI + ((long)r * CH + c8) * 4 + off);
+                sm += v.x; sq += v.y;
+            }
+        }
+        const float mean = sm / (float)(RB * cpg);
+        const long img = m0 / OHW, sl = (m0 - img * OHW) / RB;
+        *reinterpret_cast<float2*>(p.gnstat_out + ((img * (OHW / RB) + sl) * p.gn_groups + c0 / cpg + gl) * 2) = float2{mean, sq - sm * mean};
+    }
+}
+// Rows per block of that kernel for a problem (0: it cannot leave the summaries) and its column block
+inline int splitk_gs_rows(const IGemmParams& p, int groups) {
+    const int OHW = p.OH * p.OW;
+    if (groups <= 0 || groups > 256 || p.Cout % groups != 0) return 0;
+    const int cpg = p.Cout / groups;
+    if (!(cpg >= 8 || cpg == 4)) return 0;
+    for (int rb = 4; rb <= 16; rb <<= 1)
+        if (OHW % rb == 0 && OHW / rb <= 64) return rb;
+    return 0;
+}
+inline int splitk_gs_cols(const IGemmParams& p) {
+    const int cpg = p.Cout / p.gn_groups;
+    int unit = cpg;
+    while (unit % 8 != 0) unit += cpg;                       // lcm(channels per group, 8)
+    int cb = unit;
+    while (cb + unit <= 320 && cb + unit <= p.Cout) cb += unit;
+    return cb;
+}
+inline int launch_splitk_epilogue(const IGemmParams& p, const float* partial, int splits, hipStream_t s) {
+    const int rb = p.gnstat_out ? splitk_gs_rows(p, p.gn_groups) : 0;
+    if (rb) {
+        const int cb = splitk_gs_cols(p);
+        const size_t lds = (size_t)rb * (cb / 8) * 16;
+        hipLaunchKernelGGL(splitk_epilogue_gs_kernel, dim3(p.M / rb, cdiv(p.Cout, cb)), dim3(256), lds, s, p, partial, splits, rb, cb);
+    } else {
+        const long total = (long)p.M * (p.Cout / 8);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p, partial, splits);
+    }
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with the A operand kept in LDS across the nine taps.
 //
@@ -1004,13 +1114,7 @@ int launch_halo_t(const IGemmParams& p, float* partial, int splits, hipStream_t 
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, GNF, KHU>), dim3(tiles, eff_splits), dim3(512), lds, s, q, eff_splits > 1 ? partial : nullptr,
                        per);
     SD_HIP_CHECK(hipGetLastError());
-    if (eff_splits > 1) {
-        const long total = (long)p.M * (p.Cout / 8);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p, partial, eff_splits);
-        SD_HIP_CHECK(hipGetLastError());
-    }
+    if (eff_splits > 1) return launch_splitk_epilogue(p, partial, eff_splits, s);
     return 0;
 }
 
@@ -1050,13 +1154,7 @@ int launch_v2p(const IGemmParams& p, float* partial, int splits, hipStream_t s) 
     hipLaunchKernelGGL((igemm2_kernel<BM, BN, WM, WN, STAGES, PW, STAG, BKT>), dim3(tiles, eff_splits), dim3(64 * WM * WN), lds, s,
                        q, eff_splits > 1 ? partial : nullptr, per);
     SD_HIP_CHECK(hipGetLastError());
-    if (eff_splits > 1) {
-        const long total = (long)p.M * (p.Cout / 8);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, p, partial, eff_splits);
-        SD_HIP_CHECK(hipGetLastError());
-    }
+    if (eff_splits > 1) return launch_splitk_epilogue(p, partial, eff_splits, s);
     return 0;
 }
 
@@ -1186,7 +1284,13 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
     static float sentinel;
     q.gnstat_out = &sentinel;
     igemm2_pick(q, &v, &sp);
-    if (sp > 1 || v == 13 || v == 14) return false;
+    if (v == 13 || v == 14) return false;
+    if (sp > 1) {                                       // split-K: the reduction kernel leaves them
+        const int rb = splitk_gs_rows(p, groups);
+        if (!rb) return false;
+        *rows = rb;
+        return true;
+    }
     if ((v == 10 || v == 15) && !halo_supported(p)) v = 7;
     int bm, bn;
     tile_dims(v, &bm, &bn);

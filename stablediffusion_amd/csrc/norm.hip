@@ -5,6 +5,8 @@
 // Replaces aten group_norm / layer_norm + silu issued by diffusers' ResnetBlock2D, Transformer2DModel,
 // BasicTransformerBlock and the VAE decoder under the call sites
 // /root/reference/pipelines/sd_unified_pipeline.py:475-482 and :523.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sd {
@@ -250,6 +252,167 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
 }
 
+
+// Apply pass, channel-blocked (round 3): one block = NV x rows_par pixels x one channel block of CB channels (CB as
+// in the statistics kernel: a multiple of lcm(channels per group, 8), at most 512).  Against gn_apply_kernel, whose
+// every block built scale / shift for ALL C channels and merged the summaries of ALL groups in its prologue, a block's
+// prologue here only covers its own groups, and a thread keeps the scale / shift of its eight channels in registers
+// (no LDS table): the small maps (8 x 8 ... 32 x 32, where the prologue was most of the block) run at a few us.
+template <int NV>
+__global__ __launch_bounds__(256) void gn_apply2_kernel(const half_t* __restrict__ x, long ldx, const float* __restrict__ part,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        half_t* __restrict__ y, long ldy, long HW, int C, int G, int S,
+                                                        long stat_rows, int CB, float eps, int silu) {
+    __shared__ float st[128 * 2];
+    __shared__ float red[256 * 3];
+    const int n = blockIdx.z, tid = threadIdx.x;
+    const int c0 = blockIdx.y * CB;
+    const int cw = (C - c0 < CB) ? C - c0 : CB;
+    const int CCB = cw >> 3;
+    const int rows_par = 256 / CCB;
+    const int chunk = tid % CCB, prow = tid / CCB;
+    const bool active = prow < rows_par;
+    const long row0 = (long)blockIdx.x * rows_par * NV;
+    const half_t* xb = x + ((long)n * HW) * ldx + c0 + chunk * 8;
+    h8 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const long pr = row0 + prow + (long)k * rows_par;
+        if (active && pr < HW) v[k] = *reinterpret_cast<const h8*>(xb + pr * ldx);
+    }
+    const int cpg = C / G;
+    const int ng = cw / cpg, g0 = c0 / cpg;
+    const int parts = 256 / ng;
+    // (the affine of this thread's eight channels: loaded here so that its round trip overlaps the summaries')
+    const int cch = active ? c0 + chunk * 8 : 0;
+    const f4 ga = *reinterpret_cast<const f4*>(gamma + cch), gb = *reinterpret_cast<const f4*>(gamma + cch + 4);
+    const f4 ba = *reinterpret_cast<const f4*>(beta + cch), bb = *reinterpret_cast<const f4*>(beta + cch + 4);
+    {
+        const int gi = tid % ng, pi = tid / ng;
+        if (pi < parts) {
+            float nA = 0.f, mA = 0.f, qA = 0.f;
+            const float* src = part + ((long)n * S * G + g0 + gi) * 2;
+            for (int k = pi; k < S; k += parts) {
+                long rows = HW - (long)k * stat_rows;
+                if (rows > stat_rows) rows = stat_rows;
+                chan_merge(nA, mA, qA, (float)rows * (float)cpg, src[(long)k * G * 2], src[(long)k * G * 2 + 1]);
+            }
+            red[(pi * ng + gi) * 3] = nA; red[(pi * ng + gi) * 3 + 1] = mA; red[(pi * ng + gi) * 3 + 2] = qA;
+        }
+    }
+    __syncthreads();
+    if (tid < ng) {
+        float nA = red[tid * 3], mA = red[tid * 3 + 1], qA = red[tid * 3 + 2];
+        for (int k = 1; k < parts; ++k) chan_merge(nA, mA, qA, red[(k * ng + tid) * 3], red[(k * ng + tid) * 3 + 1], red[(k * ng + tid) * 3 + 2]);
+        const float var = qA / ((float)HW * (float)cpg);
+        st[tid * 2] = mA;
+        st[tid * 2 + 1] = rsqrtf((var < 0.f ? 0.f : var) + eps);
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+    {
+        const float inv_cpg = 1.0f / (float)cpg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int gl = (int)(((float)(chunk * 8 + e) + 0.5f) * inv_cpg);
+            const float w = st[gl * 2 + 1] * (e < 4 ? ga[e] : gb[e - 4]);
+            sc[e] = w;
+            sh[e] = (e < 4 ? ba[e] : bb[e - 4]) - st[gl * 2] * w;
+        }
+    }
+    half_t* yb = y + ((long)n * HW) * ldy + c0 + chunk * 8;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const long pr = row0 + prow + (long)k * rows_par;
+        if (pr < HW) {
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[k][e] * sc[e] + sh[e];
+                if (silu) f = silu_f(f);
+                o[e] = (half_t)f;
+            }
+            *reinterpret_cast<h8*>(yb + pr * ldy) = o;
+        }
+    }
+}
+
+// Statistics pass with one PIVOT PER GROUP (round 3).  gn_stats_kernel keeps a pivot per (thread, channel) and then
+// merges thread, channel and slab summaries with Chan's formula -- exact, but the merges (divisions, done by the
+// 256 / rows_par threads of pixel row 0 in a serial loop) took longer than the pass over x.  Here every element of a
+// group is shifted by the SAME value, the group's first channel at the slab's first pixel (any sample of the group is
+// within a few standard deviations of its mean, which is all the shift has to achieve), so thread partials are plain
+// sums: added per group in a fixed order, then one (mean, M2) conversion.  Needs every 16-byte chunk inside at most
+// two groups (channels per group >= 8, or == 4).
+__global__ __launch_bounds__(256) void gn_stats2_kernel(const half_t* __restrict__ x, long ldx, float* __restrict__ part, long HW,
+                                                        int C, int G, int S, int CB) {
+    __shared__ float red[256 * 4];
+    const int n = blockIdx.z, s = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x;
+    const int c0 = cb * CB;
+    const int cw = (C - c0 < CB) ? C - c0 : CB;
+    const int CCB = cw >> 3;
+    const int rows_par = 256 / CCB;
+    const int chunk = tid % CCB, prow = tid / CCB;
+    const long rows_per = (HW + S - 1) / S;
+    const long p0 = (long)s * rows_per;
+    long p1 = p0 + rows_per;
+    if (p1 > HW) p1 = HW;
+    const int cpg = C / G;
+    const int ch = chunk * 8;                                // first channel of the chunk inside the block
+    const int gA = ch / cpg;                                 // local group of the chunk's first channel
+    const int split = (gA + 1) * cpg - ch;                   // channels e < split belong to gA, the rest to gA + 1
+    const half_t* img = x + ((long)n * HW) * ldx + c0;
+    const bool twog = split < 8;
+    const float pivA = (float)img[p0 * ldx + gA * cpg];
+    const float pivB = twog ? (float)img[p0 * ldx + (gA + 1) * cpg] : 0.f;
+    float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+    if (prow < rows_par) {
+        const half_t* base = img + ch;
+        long pix = p0 + prow;
+        for (; pix + 7L * rows_par < p1; pix += 8L * rows_par) {
+            h8 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const h8*>(base + (pix + (long)u * rows_par) * ldx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < split) { const float f = (float)v[u][e] - pivA; sa += f; qa += f * f; }
+                    else { const float f = (float)v[u][e] - pivB; sb += f; qb += f * f; }
+                }
+        }
+        for (; pix < p1; pix += rows_par) {
+            const h8 v = *reinterpret_cast<const h8*>(base + pix * ldx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < split) { const float f = (float)v[e] - pivA; sa += f; qa += f * f; }
+                else { const float f = (float)v[e] - pivB; sb += f; qb += f * f; }
+            }
+        }
+    }
+    *reinterpret_cast<f4*>(red + tid * 4) = f4{sa, qa, sb, qb};
+    __syncthreads();
+    const int ng = cw / cpg;
+    if (tid < ng) {
+        const int cfirst = (tid * cpg) / 8, clast = ((tid + 1) * cpg - 1) / 8;
+        float sm = 0.f, sq = 0.f;
+        for (int c8 = cfirst; c8 <= clast; ++c8) {
+            const int off = ((c8 * 8) / cpg == tid) ? 0 : 2;             // this group is the chunk's first, or its second
+            for (int r = 0; r < rows_par; ++r) {
+                const float2 v = *reinterpret_cast<const float2*>(red + (r * CCB + c8) * 4 + off);
+                sm += v.x; sq += v.y;
+            }
+        }
+        const float cnt = (float)(p1 - p0) * (float)cpg;
+        const float d = sm / cnt;
+        const float piv = (float)img[p0 * ldx + tid * cpg];
+        float* dst = part + (((long)n * S + s) * G + c0 / cpg + tid) * 2;
+        dst[0] = piv + d;
+        dst[1] = sq - sm * d;
+    }
+}
+
 // Single-pass GroupNorm for the small feature maps (HW <= 1024): one block per (sample, channel
 // unit), unit = lcm(channels-per-group, 8) channels, so 16-byte chunks and groups both tile it.
 // The block's whole [HW x unit] panel stays in registers between the statistics and the apply:
@@ -475,31 +638,51 @@ long gn_scratch_floats(int N, long HW, int C, int G) {
     return (long)N * gn_slabs(N, HW, C, G) * G * 2;
 }
 
-bool gn_wants_stats(long HW, int C, int G) { return gn_fused_unit(HW, C, G) == 0; }
+// Summaries from the producer pay from 32 x 32 maps up: below, a GroupNorm launch costs its ~5 us floor whatever it
+// reads, the single-kernel form (x read once, statistics in registers) is already there, and the producer's extra
+// work (a split-K reduction kernel that also reduces per group: +5 us) is a net loss (rocprofv3, round 3).
+bool gn_wants_stats(long HW, int C, int G) { return gn_fused_unit(HW, C, G) == 0 || HW >= 1024; }
+
+static int launch_stats_pass(const half_t* x, long ldx, int N, long HW, int C, int G, int S, float* scratch, hipStream_t s) {
+    const int CB = gn_block_channels(C, G);
+    const int cpg = C / G;
+    static const bool old = getenv("SD_GN_OLD") != nullptr;         // A/B switch: round-2 kernels
+    if (!old && (cpg >= 8 || cpg == 4))
+        hipLaunchKernelGGL(gn_stats2_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float* beta, half_t* y,
                      long ldy, int N, long HW, int C, int G, float eps, int silu, float* scratch,
                      hipStream_t s, const GnStats* pre) {
     if (C % 8 != 0 || C % G != 0 || G > 256) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
-    if (const int U = gn_fused_unit(HW, C, G)) {
-        const dim3 grid(C / U, N);
-        const int cpg = C / G;
-        if (HW <= 64)
-            hipLaunchKernelGGL((gn_fused_kernel<256, 4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, (int)HW, C, cpg, U, eps, silu);
-        else if (HW <= 256)
-            hipLaunchKernelGGL((gn_fused_kernel<256, 16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, (int)HW, C, cpg, U, eps, silu);
-        else
-            hipLaunchKernelGGL((gn_fused_kernel<1024, 16>), grid, dim3(1024), 0, s, x, ldx, gamma, beta, y, ldy, (int)HW, C, cpg, U, eps, silu);
-        SD_HIP_CHECK(hipGetLastError());
-        return 0;
+    static const bool old = getenv("SD_GN_OLD") != nullptr;             // A/B switch: round-2 kernels and choices
+    const bool have_pre = pre && pre->part && (old ? gn_fused_unit(HW, C, G) == 0 : gn_wants_stats(HW, C, G));
+    // summaries already there (left by the producing convolution's epilogue): apply pass only, at every map size;
+    // otherwise the small maps take the single-kernel form (x read once), the big ones statistics + apply
+    if (!have_pre) {
+        if (const int U = gn_fused_unit(HW, C, G)) {
+            const dim3 grid(C / U, N);
+            const int cpg = C / G;
+            if (HW <= 64)
+                hipLaunchKernelGGL((gn_fused_kernel<256, 4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, (int)HW, C, cpg, U, eps, silu);
+            else if (HW <= 256)
+                hipLaunchKernelGGL((gn_fused_kernel<256, 16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, (int)HW, C, cpg, U, eps, silu);
+            else
+                hipLaunchKernelGGL((gn_fused_kernel<1024, 16>), grid, dim3(1024), 0, s, x, ldx, gamma, beta, y, ldy, (int)HW, C, cpg, U, eps, silu);
+            SD_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
     }
     int S = gn_slabs(N, HW, C, G);
     long stat_rows = (HW + S - 1) / S;
     const float* part = scratch;
-    if (pre && pre->part) {
-        // the producing convolution's epilogue already wrote one (mean, M2) summary per tile of
-        // pre->rows pixels: no statistics pass over x.  Many tiles per image are merged once, by a small
-        // kernel, instead of by every apply block.
+    if (have_pre) {
+        // one (mean, M2) summary per tile of pre->rows pixels: no statistics pass over x.  Many tiles per image are
+        // merged once, by a small kernel, instead of by every apply block.
         part = pre->part; S = pre->S; stat_rows = pre->rows;
         if (S > 64) {
             hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, s, part, scratch, S, G, stat_rows, HW, C / G);
@@ -507,8 +690,23 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
             part = scratch; S = 1; stat_rows = HW;
         }
     } else {
-        const int CB = gn_block_channels(C, G);
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
+        const int rc = launch_stats_pass(x, ldx, N, HW, C, G, S, scratch, s);
+        if (rc) return rc;
+    }
+    const int CB = gn_block_channels(C, G);
+    if (!old && CB / (C / G) <= 128) {
+        // channel-blocked apply: rows per block = (256 / chunks per row) x NV, NV the largest of 8 / 4 / 2 / 1 that still
+        // leaves about 1024 blocks (or one pixel row group per block on the small maps)
+        const int cblocks = cdiv(C, CB);
+        const int rows_par = 256 / (CB / 8) > 0 ? 256 / (CB / 8) : 1;
+        int nv = 8;
+        while (nv > 1 && cdiv(HW, (long)rows_par * nv) * cblocks * N < 1024) nv >>= 1;
+        const dim3 grid((unsigned)cdiv(HW, (long)rows_par * nv), cblocks, N);
+#define SD_GN_APPLY2(NVV) hipLaunchKernelGGL((gn_apply2_kernel<NVV>), grid, dim3(256), 0, s, x, ldx, part, gamma, beta, y, ldy, HW, C, G, S, stat_rows, CB, eps, silu)
+        if (nv == 8) SD_GN_APPLY2(8); else if (nv == 4) SD_GN_APPLY2(4); else if (nv == 2) SD_GN_APPLY2(2); else SD_GN_APPLY2(1);
+#undef SD_GN_APPLY2
+        SD_HIP_CHECK(hipGetLastError());
+        return 0;
     }
     // apply: rows per block so that a thread holds <= GN_APPLY_NV chunks, and >= ~512 blocks overall
     const int CC = C / 8;
@@ -526,9 +724,8 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
 int launch_gn_stats(const half_t* x, long ldx, int N, long HW, int C, int G, float* scratch, GnStats* st, hipStream_t s) {
     if (C % 8 != 0 || C % G != 0 || G > 256) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
     const int S = gn_slabs(N, HW, C, G);
-    const int CB = gn_block_channels(C, G);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(C, CB), S, N), dim3(256), 0, s, x, ldx, scratch, HW, C, G, S, CB);
-    SD_HIP_CHECK(hipGetLastError());
+    const int rc = launch_stats_pass(x, ldx, N, HW, C, G, S, scratch, s);
+    if (rc) return rc;
     st->part = scratch; st->S = S; st->rows = (HW + S - 1) / S;
     return 0;
 }

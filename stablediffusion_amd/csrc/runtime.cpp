@@ -436,6 +436,8 @@ void op_groupnorm(Ctx& c, const NormW& n, View x, View y, int N, long HW, int G,
                   const GnStatBuf* pre) {
     float* scratch = c.arena->alloc_f(gn_scratch_floats(N, HW, n.C, G));
     if (c.dry || c.err) return;
+    static const bool gn_old = getenv("SD_GN_OLD") != nullptr;
+    (void)gn_old;
     const GnStats* st = (pre && pre->st.part && gn_wants_stats(HW, n.C, G)) ? &pre->st : nullptr;
     // bytes really moved: the single-kernel form and the apply pass read x and write y; only the
     // stand-alone statistics pass reads x once more

@@ -261,8 +261,9 @@ void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, 
     View h2(a.alloc_h(M * r.cout), r.cout, r.cout);
     // Both GroupNorm + SiLU pairs run inside the convolution that consumes them where the launch allows (op_gn_conv);
     // conv1's epilogue leaves the GroupNorm summaries of h2 for norm2, conv2's those of `out` for whoever normalises it.
+    const long HW = (long)H * W;
     ConvFuse f1;
-    f1.gn_out = ctx_gnbuf(c);
+    f1.gn_out = gn_wants_stats(HW, r.cout, G) ? ctx_gnbuf(c) : nullptr;
     f1.gn_groups = G;
     op_gn_conv(c, r.n1, r.c1, x, N, H, W, h2, G, eps, 1, x_stats, tproj ? tproj + r.temb_off : nullptr, tproj_ld, nullptr, &f1);
     View res = x;
@@ -271,7 +272,7 @@ void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, 
         op_conv(c, r.sc, x, N, H, W, res);
     }
     ConvFuse f2;
-    f2.gn_out = out_stats ? ctx_gnbuf(c) : nullptr;
+    f2.gn_out = (out_stats && gn_wants_stats(HW, r.cout, G)) ? ctx_gnbuf(c) : nullptr;
     f2.gn_groups = G;
     op_gn_conv(c, r.n2, r.c2, h2, N, H, W, out, G, eps, 1, f1.gn_out, nullptr, 0, &res, &f2);
     if (out_stats) *out_stats = f2.gn_out;
@@ -340,7 +341,7 @@ void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out
         View tmp = cur; cur = nxt; nxt = tmp;
     }
     ConvFuse fo;
-    fo.gn_out = out_stats ? ctx_gnbuf(c) : nullptr;
+    fo.gn_out = (out_stats && gn_wants_stats(T, C, G)) ? ctx_gnbuf(c) : nullptr;
     fo.gn_groups = G;
     op_conv(c, t.pout, cur, N, H, W, out, 1, 0, nullptr, 0, &x, 0, -1, 0, &fo);
     if (out_stats) *out_stats = fo.gn_out;
@@ -451,7 +452,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         if (go && !c.err) c.err = launch_im2col_nchw3x3(sample, col, B, cfg.in_channels, H, W, (int)conv_in.K, s);
         ConvW pw = conv_in; pw.ks = 1;
         ConvFuse f;
-        f.gn_out = ctx_gnbuf(c);
+        f.gn_out = gn_wants_stats((long)H * W, boc[0], G) ? ctx_gnbuf(c) : nullptr;
         f.gn_groups = G;
         op_conv(c, pw, View(col, conv_in.K, (int)conv_in.K), B, H, W, skip_view(skip_i), 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
         xs = f.gn_out;
@@ -482,7 +483,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         if (i != nb - 1) {
             View dst = skip_view(skip_i++);
             ConvFuse f;
-            f.gn_out = ctx_gnbuf(c);
+            f.gn_out = gn_wants_stats((long)(h / 2) * (w / 2), down_ds[i].cout, G) ? ctx_gnbuf(c) : nullptr;
             f.gn_groups = G;
             op_conv(c, down_ds[i], x, B, h, w, dst, 2, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
             xs = f.gn_out;

@@ -170,7 +170,7 @@ void VAE::run_attn(Ctx& c, const VaeAttn& at, View x, int N, int H, int W, View 
     View o(a.alloc_h(M * C), C, C);
     op_attention(c, qkv.slice(0, C), qkv.slice(C, C), qkv.slice(2 * C, C), o, N, H * W, H * W, 1, C);
     ConvFuse fo;
-    fo.gn_out = out_stats ? ctx_gnbuf(c) : nullptr;
+    fo.gn_out = (out_stats && gn_wants_stats((long)H * W, C, cfg.norm_num_groups)) ? ctx_gnbuf(c) : nullptr;
     fo.gn_groups = cfg.norm_num_groups;
     op_conv(c, at.out, o, N, H, W, out, 1, 0, nullptr, 0, &x, 0, -1, 0, &fo);
     if (out_stats) *out_stats = fo.gn_out;
@@ -192,7 +192,7 @@ int VAE::run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w) {
     ctx_gnpool_init(c, B, (long)h * w << (2 * (nb - 1)), G);
     GnStatBuf* xs = nullptr;
     auto gn_fuse = [&](ConvFuse& f, long HW, int C) {
-        f.gn_out = ctx_gnbuf(c);
+        f.gn_out = gn_wants_stats(HW, C, G) ? ctx_gnbuf(c) : nullptr;
         f.gn_groups = G;
     };
 
@@ -269,7 +269,7 @@ int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, in
     ctx_gnpool_init(c, B, (long)H * W, G);
     GnStatBuf* xs = nullptr;
     auto gn_fuse = [&](ConvFuse& f, long HW, int C) {
-        f.gn_out = ctx_gnbuf(c);
+        f.gn_out = gn_wants_stats(HW, C, G) ? ctx_gnbuf(c) : nullptr;
         f.gn_groups = G;
     };
     View cur(a.alloc_h(M * boc[0]), boc[0], boc[0]);

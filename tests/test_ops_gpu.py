@@ -179,8 +179,8 @@ CONV_GN_CASES = [
     # N, H, W, Cin, Cout, k, stride, up, residual, expect the epilogue path
     # `expect`: 1 = the tuned table gives this shape a tile whose epilogue can leave the summaries (C2's own
     # shapes), None = whichever tile / split-K the heuristic picks, the numbers must not depend on it
-    (8, 64, 64, 320, 320, 3, 1, 0, True, 1),      # UNet level 0 resnet conv2: the tuned table swaps the halo kernel (which
-                                                  # cannot leave them) for the best tile that can when its lead is small
+    (8, 64, 64, 320, 320, 3, 1, 0, True, 1),      # UNet level 0 resnet conv2: the 160-column halo kernel in its
+                                                  # rows-as-loop form (the unrolled one has no registers left for them)
     (8, 64, 64, 320, 320, 1, 1, 0, True, 1),      # Transformer2D proj_out (+residual) -> conv_norm_out / next block
     (2, 64, 64, 320, 320, 3, 1, 0, True, None),
     (2, 64, 64, 64, 320, 1, 1, 0, False, None),   # conv_in as the im2col GEMM (pointwise)
@@ -189,6 +189,10 @@ CONV_GN_CASES = [
     (1, 128, 128, 128, 512, 3, 2, 0, False, None),   # stride 2 (encoder / UNet downsample), cpg = 16
     (2, 32, 32, 640, 640, 3, 1, 0, True, None),   # small map: the single-kernel GroupNorm needs no summaries
     (1, 40, 40, 64, 320, 3, 1, 0, False, None),   # 1600 pixels per image
+    (8, 16, 16, 1280, 1280, 3, 1, 0, True, 1),    # UNet 16 x 16 level: split-K, summaries from the reduction kernel
+    (8, 8, 8, 1280, 1280, 3, 1, 0, True, 1),      # 8 x 8 level: split-K 8, 16-pixel slabs (4 per image)
+    (8, 32, 32, 960, 640, 3, 1, 0, False, None),  # 32 x 32 level, halo kernel split over the slabs
+    (2, 16, 16, 1280, 1280, 1, 1, 0, True, None), # proj_out at 16 x 16
 ]
 
 
