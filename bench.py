@@ -394,8 +394,12 @@ def main():
         if pooled is not None:
             pooled.zero_(); npooled.zero_()
 
+    # the text embeddings of the run: ONE RCCL broadcast from rank 0 (once per run), then every
+    # pass works on this rank's slice; the all-gather of the decoded images is part of every pass
+    sdd.broadcast_tensors([pe_full, ne_full] + [t for t in (pooled, npooled) if t is not None])
+
     def one_pass():
-        return sdd.sharded_txt2img(pipe, model, lat_full, pe_full, ne_full, rank, n_gpus, pooled, npooled,
+        return sdd.sharded_txt2img(pipe, model, lat_full, pe_full, ne_full, rank, n_gpus, pooled, npooled, broadcast=False,
                                    num_inference_steps=args.denoise_steps, guidance_scale=args.guidance,
                                    height=args.res, width=args.res)
 
@@ -421,7 +425,7 @@ def main():
         lat_big = torch.randn(total, 4, lhw, lhw, generator=torch.Generator().manual_seed(0)).half().to(device)
 
         def big_pass():
-            return sdd.sharded_txt2img(pipe, model, lat_big, pe_full, ne_full, rank, n_gpus, pooled, npooled,
+            return sdd.sharded_txt2img(pipe, model, lat_big, pe_full, ne_full, rank, n_gpus, pooled, npooled, broadcast=False,
                                        num_inference_steps=args.denoise_steps, guidance_scale=args.guidance,
                                        height=lres, width=lres)
         big_pass()

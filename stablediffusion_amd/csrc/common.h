@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 typedef _Float16 half_t;
@@ -24,14 +25,12 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // GPUs (HipUNet2DConditionModel(device="cuda:1")), so "already set" is remembered per (launcher, device).
 // Setting it twice is harmless, so a racy first call from two threads only costs a repeat.
 struct PerDeviceOnce {
-    unsigned long long done = 0;
+    std::atomic<unsigned long long> done{0};
     bool first() {
         int d = 0;
         (void)hipGetDevice(&d);
         const unsigned long long bit = 1ull << (d & 63);
-        const bool was = (done & bit) != 0;
-        done |= bit;
-        return !was;
+        return (done.fetch_or(bit) & bit) == 0;
     }
 };
 

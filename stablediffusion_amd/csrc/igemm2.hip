@@ -14,7 +14,9 @@
 //     splitk_epilogue_kernel reduces the slabs in a fixed order (deterministic) and applies
 //     bias / time-embedding row add / residual / GEGLU.
 // Tile variants (BM x BN, waves, stages) are chosen per shape by pick_variant().
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "kernels.h"
 
@@ -1096,8 +1098,10 @@ int launch_halo_t(const IGemmParams& p, float* partial, int splits, hipStream_t 
     if (lds < epi) lds = epi;
     if (lds > 160 * 1024) { set_error("conv3x3_halo_kernel: LDS budget"); return 1; }
     static size_t attr_by_dev[64] = {};
+    static std::mutex attr_mu;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
     size_t& attr = attr_by_dev[dev & 63];
     if (lds > attr) {
         SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BN, GNF, KHU>),
@@ -1165,8 +1169,10 @@ int launch_v2(const IGemmParams& p, float* partial, int splits, hipStream_t s) {
     return launch_v2p<BM, BN, WM, WN, STAGES, false, STAG, BKT>(p, partial, splits, s);
 }
 
-int g_force_variant = -1;
-int g_force_splits = 0;
+// process-wide tuner / test override (sd_igemm_force): atomics, so that two handles driven from two threads see a
+// consistent value each; the tile choice itself is per launch
+std::atomic<int> g_force_variant{-1};
+std::atomic<int> g_force_splits{0};
 
 }  // namespace
 
@@ -1255,7 +1261,7 @@ void igemm2_pick(const IGemmParams& p, int* variant, int* splits) {
     if ((*variant == 13 || *variant == 14) && !ws_ok) { *variant = p.geglu ? 1 : 2; *splits = 1; }     // (forced on a problem it does not take)
     // (with a residual the streamed tiles win by 1-6 us per launch -- profiles/r02_wsgemm.txt -- so those stay on them
     // unless variant 13 is forced)
-    if (g_force_variant < 0 && ws_ok && !p.res && wsgemm_enabled()) { *variant = p.geglu ? 14 : 13; *splits = 1; }
+    if (g_force_variant.load() < 0 && ws_ok && !p.res && wsgemm_enabled()) { *variant = p.geglu ? 14 : 13; *splits = 1; }
     if (*variant == 13 && p.geglu) *variant = 14;
     if (*variant == 14 && !p.geglu) *variant = 13;
 }
@@ -1302,9 +1308,9 @@ bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows) {
 }
 
 static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits) {
-    if (g_force_variant >= 0) {
-        *variant = g_force_variant;
-        *splits = g_force_splits > 0 ? g_force_splits : 1;
+    if (g_force_variant.load() >= 0) {
+        *variant = g_force_variant.load();
+        *splits = g_force_splits.load() > 0 ? g_force_splits.load() : 1;
         if (p.geglu && *variant != 0 && *variant != 1 && *variant != 6 && *variant != 13 && *variant != 14) *variant = 1;
         if (p.geglu || p.act) *splits = 1;
         if ((*variant == 10 || *variant == 15) && !halo_supported(p)) *variant = 7;

@@ -61,6 +61,7 @@ struct IGemmParams {
     float gni_eps = 0.f;
     int gni_silu = 0;
     const float* gni_gb = nullptr;
+    int dbg_unchecked = 0;          // tests: wsgemm's residual descriptor without its range check
 };
 // Whether launch_igemm2 can apply a GroupNorm of `groups` groups to this problem's input (p.gni_* set by the caller).
 bool igemm2_gn_fusable(const IGemmParams& p, int groups);

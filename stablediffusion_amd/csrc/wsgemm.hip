@@ -34,6 +34,8 @@
 // epilogue parts in opposite order.
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sd {
@@ -104,8 +106,11 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(IGemmParams p, int tiles_m,
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(LN ? p.ln_stat : p.bias), 0, LN ? (int)((long)p.M * parts * 8) : 0, 0x00020000);
 
+    // (p.dbg_unchecked, tests only: the residual's descriptor without its range check -- every residual load then has to
+    // be in range by the index arithmetic alone, which tests/test_ops_gpu.py::test_wsgemm_residual_loads_need_no_range_check
+    // verifies bit for bit; see profiles/r02_wsgemm.txt for the fault this settles)
     __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<half_t*>(RES ? p.res : p.x), 0, RES ? (int)((long)p.M * p.ldres * 2) : 0, 0x00020000);
+        const_cast<half_t*>(RES ? p.res : p.x), 0, RES ? (p.dbg_unchecked ? 0x7ffffff0 : (int)((long)p.M * p.ldres * 2)) : 0, 0x00020000);
 
     // GEGLU: LDS rows [hidden 0-31 | gate 0-31 | hidden 32-63 | gate 32-63] of the packed [64 hidden | 64 gate]
     auto perm = [](int r) { return !GEGLU || r < 32 || r >= 96 ? r : (r < 64 ? r + 32 : r - 32); };
@@ -398,6 +403,7 @@ int launch_ws(const IGemmParams& p, hipStream_t s) {
     }
     IGemmParams q = p;
     q.rowstat_parts = 2 * (p.Cout / BN);
+    if (RES && getenv("SD_WS_RES_UNCHECKED")) q.dbg_unchecked = 1;       // (test switch, read per launch)
     const int tiles_m = p.M / 128, tiles_n = p.Cout / BN;
     hipLaunchKernelGGL((wsgemm_kernel<BN, GEGLU, LN, RES, RS>), dim3(256), dim3(512), lds, s, q, tiles_m, tiles_n);
     SD_HIP_CHECK(hipGetLastError());

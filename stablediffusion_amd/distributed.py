@@ -75,16 +75,25 @@ def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0):
 
 
 def all_gather_batch(local: torch.Tensor, total: int) -> torch.Tensor:
-    """Concatenate per-rank shards (possibly uneven) along dim 0 on every rank."""
+    """Concatenate per-rank shards along dim 0 on every rank.  Even shards (the benchmark's and any batch that is a
+    multiple of the world size): ONE `all_gather_into_tensor` straight into the [total, ...] result -- one RCCL
+    collective over xGMI, no list of temporaries, no host-side padding.  Uneven shards are padded to the largest."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return local
     world = dist.get_world_size()
     sizes = [shard_bounds(total, r, world) for r in range(world)]
     max_n = max(hi - lo for lo, hi in sizes)
+    dev = local.device
+    if all(hi - lo == max_n for lo, hi in sizes):
+        src = local.contiguous()
+        if _host_staged() and src.is_cuda:
+            src = src.cpu()
+        out = torch.empty((total,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src)
+        return out.to(dev)
     pad = local
     if local.shape[0] < max_n:
         pad = torch.cat([local, local.new_zeros((max_n - local.shape[0],) + tuple(local.shape[1:]))])
-    dev = pad.device
     if _host_staged() and pad.is_cuda:
         pad = pad.cpu()
     out = [torch.empty_like(pad) for _ in range(world)]
@@ -108,15 +117,17 @@ def max_over_ranks(x: float, device) -> float:
 def sharded_txt2img(pipeline, model, latents_full: torch.Tensor, prompt_embeds_full: torch.Tensor,
                     negative_embeds_full: torch.Tensor, rank: int, world: int,
                     pooled_full: Optional[torch.Tensor] = None, negative_pooled_full: Optional[torch.Tensor] = None,
-                    **call_kwargs) -> torch.Tensor:
+                    broadcast: bool = True, **call_kwargs) -> torch.Tensor:
     """Run the pipeline on this rank's slice of the batch and return the full gathered batch.
 
     `latents_full` is generated once for the whole batch from the single seeded generator
-    (`sd_unified_pipeline.py:773-781` semantics) so sharded == unsharded per sample.
+    (`sd_unified_pipeline.py:773-781` semantics) so sharded == unsharded per sample.  `broadcast=False`: the text
+    embeddings were broadcast already (a caller that runs several passes over the same prompts broadcasts once).
     """
     total = latents_full.shape[0]
     extra = [t for t in (pooled_full, negative_pooled_full) if t is not None]
-    broadcast_tensors([prompt_embeds_full, negative_embeds_full] + extra)
+    if broadcast:
+        broadcast_tensors([prompt_embeds_full, negative_embeds_full] + extra)
     lat = shard(latents_full, rank, world)
     pe = shard(prompt_embeds_full, rank, world)
     ne = shard(negative_embeds_full, rank, world)

@@ -124,6 +124,12 @@ class HipUNet2DConditionModel:
         the packed weights are immutable once finalized)."""
         return type(self)(self.cfg, self.device).load_state_dict(state_dict)
 
+    def rebuild_factory(self):
+        """`rebuild` without a reference to this engine: the LoRA re-fuse drops the old engine (and its device memory)
+        BEFORE it packs the new one (peak memory was twice the UNet weights)."""
+        cls, cfg, dev = type(self), self.cfg, self.device
+        return lambda state_dict: cls(cfg, dev).load_state_dict(state_dict)
+
     def memory(self):
         w, s = C.c_int64(), C.c_int64()
         _lib.check(self._lib.sd_unet_memory(self._h, C.byref(w), C.byref(s)), "sd_unet_memory")
@@ -132,6 +138,7 @@ class HipUNet2DConditionModel:
     def use_graph(self, enable: bool = True):
         """Replay the forward from a captured hipGraph (one host call per step instead of ~480)."""
         _lib.check(self._lib.sd_unet_use_graph(self._h, int(bool(enable))), "sd_unet_use_graph")
+        self._graph_on = bool(enable)          # (carried over to the engine a LoRA re-fuse builds)
         return self
 
     def text_kv_cache(self, enable: bool = True):

@@ -34,12 +34,16 @@ class SDModelWrapper:
 
     def __init__(self, base=None, vae=None, text_encoder=None, tokenizer=None, scheduler=None,
                  text_encoder_2=None, tokenizer_2=None, model_type: str = "sd15", device: str = "cuda",
-                 model_name: Optional[str] = None, unet_state_dict: Optional[Dict[str, torch.Tensor]] = None):
+                 model_name: Optional[str] = None, unet_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 text_encoder_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 text_encoder_2_state_dict: Optional[Dict[str, torch.Tensor]] = None):
         self.base = base
-        # host copy of the UNet weights the LoRA adapters are folded into (load_lora_weights); the engine
+        # host copies of the weights the LoRA adapters are folded into (load_lora_weights); the engine
         # itself keeps only its packed device copy
         self._lora = None
+        self._lora_applied = None        # signature of the adapter state the sub-models were last built from
         self._unet_sd = unet_state_dict
+        self._te_sd = {"text_encoder": text_encoder_state_dict, "text_encoder_2": text_encoder_2_state_dict}
         self.vae = vae
         self.text_encoder = text_encoder
         self.tokenizer = tokenizer
@@ -50,7 +54,7 @@ class SDModelWrapper:
         # the reference leaves `scheduler_name` unset until the first set_scheduler (hasattr check,
         # models/stable_diffusion.py:200); it is only pre-set here when it is known to be true, so that
         # set_scheduler("euler") on a wrapper built around another scheduler really switches
-        if isinstance(self.scheduler, _sched.EulerDiscreteScheduler):
+        if type(self.scheduler) is _sched.EulerDiscreteScheduler:     # (not its euler_a subclass: ADVICE r2)
             self.scheduler_name = "euler"
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
         # models/stable_diffusion.py:96-101
@@ -77,39 +81,75 @@ class SDModelWrapper:
             if self._unet_sd is None:
                 raise ValueError("LoRA needs the UNet's base weights on the host: build the wrapper with "
                                  "unet_state_dict=... (the engine keeps only its packed device copy)")
+            if not hasattr(self.base, "rebuild"):
+                raise ValueError(f"{type(self.base).__name__} cannot be rebuilt from a state dict")
             from .lora import LoraAdapters
-            self._lora = LoraAdapters(self._unet_sd)
+            f = getattr(self.base, "rebuild_factory", None)
+            self._base_factory = f() if f else self.base.rebuild
+            self._lora = LoraAdapters(self._unet_sd, self._te_sd["text_encoder"], self._te_sd["text_encoder_2"])
         return self._lora
 
-    def _refuse(self):
+    def apply_adapters(self):
+        """Rebuild the sub-models the adapters touch from the fused weights -- once per change of the adapter state,
+        however many load / set / delete calls produced it (the reference's `load_loras` is delete + N loads + set:
+        one re-pack here, not N + 2).  Called by the pipeline before it runs; callable by hand."""
+        if self._lora is None:
+            return
+        sig = self._lora.signature()
+        if sig == self._lora_applied:
+            return
         if not hasattr(self.base, "rebuild"):
             raise ValueError(f"{type(self.base).__name__} cannot be rebuilt from a state dict")
-        self.base = self.base.rebuild(self._adapters().fused())
+        fused = self._lora.fused("unet")
+        old = self.base
+        graph = bool(getattr(old, "_graph_on", False))
+        self.base = None                     # the old engine's device memory goes before the new one is packed
+        del old
+        self.base = self._rebuild_from(fused, graph)
+        for part in ("text_encoder", "text_encoder_2"):
+            if self._te_sd[part] is not None and (self._lora.touches(part) or self._lora_applied is not None):
+                enc = getattr(self, part, None)
+                sd = self._lora.fused(part)
+                if hasattr(enc, "rebuild"):
+                    setattr(self, part, enc.rebuild(sd))
+                elif hasattr(enc, "load_state_dict"):
+                    enc.load_state_dict(sd, strict=False)
+                else:
+                    raise ValueError(f"{type(enc).__name__} cannot take fused text-encoder LoRA weights")
+        self._lora_applied = sig
+
+    def _rebuild_from(self, fused, graph):
+        base = self._base_factory(fused)
+        if graph and hasattr(base, "use_graph"):
+            base.use_graph(True)
+        return base
+
+    def _refuse(self):
+        # (kept for callers that want the rebuild now; load / set / delete only mark the state changed)
+        self.apply_adapters()
 
     def load_lora_weights(self, pretrained_model_name_or_path_or_dict, adapter_name: Optional[str] = None, **kwargs):
-        """`pytorch_lora_weights.safetensors` (a file, a folder holding one, or a dict) -> a named adapter,
-        active at weight 1 as in diffusers; `set_adapters` changes names / weights."""
+        """`pytorch_lora_weights.safetensors` or a kohya / A1111 file (a file, a folder holding one, or a dict) -> a named
+        adapter, active at weight 1 as in diffusers; `set_adapters` changes names / weights.  UNet and text-encoder
+        layers (`stable_diffusion.py:259-295`); the sub-models are rebuilt lazily (apply_adapters)."""
         self._adapters().load(pretrained_model_name_or_path_or_dict, adapter_name)
-        self._refuse()
 
     def set_adapters(self, adapter_names, adapter_weights=None):
         self._adapters().set(adapter_names, adapter_weights)
-        self._refuse()
 
     def delete_adapters(self, adapter_names):
         self._adapters().delete(adapter_names)
-        self._refuse()
 
     def get_list_adapters(self):
         return {"base": self._lora.names()} if self._lora is not None and self._lora.names() else {}
 
     def set_lora_scale(self, scale: float):
         """`cross_attention_kwargs={"scale": s}` (sd_unified_pipeline.py:190): a run-time multiplier on every
-        active adapter in diffusers; here a re-fuse, done only when the value changes."""
-        if self._lora is None or not self._lora.names() or float(scale) == self._lora.scale:
+        active adapter in diffusers, in effect for ONE call (the pipeline passes 1.0 when the kwarg is absent);
+        here part of the adapter state, re-fused only when the value changes."""
+        if self._lora is None:
             return
         self._lora.scale = float(scale)
-        self._refuse()
 
     def set_scheduler(self, scheduler_name):
         """Registry of models/stable_diffusion.py:199-227 (names the engine's host code implements)."""
@@ -199,9 +239,13 @@ class StableDiffusionUnifiedPipeline:
         if model.device != self.device:
             model.to(self.device)
         self.model = model
-        if cross_attention_kwargs is not None and cross_attention_kwargs.get("scale", None) is not None \
-                and hasattr(model, "set_lora_scale"):
-            model.set_lora_scale(cross_attention_kwargs["scale"])      # `:190`: the LoRA scale of this call
+        if hasattr(model, "set_lora_scale"):
+            # `:190`: the LoRA scale of THIS call -- 1.0 when the kwarg is absent (diffusers / peft un-scale after the
+            # forward; a scale left over from an earlier call would be a different model: ADVICE r2)
+            lora_scale = cross_attention_kwargs.get("scale", None) if cross_attention_kwargs is not None else None
+            model.set_lora_scale(1.0 if lora_scale is None else lora_scale)
+        if hasattr(model, "apply_adapters"):
+            model.apply_adapters()
         if image is not None and mask_image is None:
             # img2img keeps the image's own size (`:238` preprocesses without height / width); PIL, numpy and
             # tensor inputs alike go through the image processor (rounded down to a multiple of the VAE factor)
@@ -331,6 +375,10 @@ class StableDiffusionUnifiedPipeline:
         # projections for the duration of this loop (switched off again right after it)
         kv_cache = getattr(model.base, "text_kv_cache", None)
         if kv_cache is not None:
+            # the cache is keyed by the buffer's address: hand the engine ONE fp16 contiguous tensor for the whole loop
+            # (a per-step conversion inside the shim would make a fresh temporary each step: ADVICE r2)
+            if prompt_embeds.device.type == "cuda" and (prompt_embeds.dtype != torch.float16 or not prompt_embeds.is_contiguous()):
+                prompt_embeds = prompt_embeds.to(torch.float16).contiguous()
             kv_cache(True)
         fused_step = self._fused_step_available(model, latents, num_channels_unet)
         fused_hist = None

@@ -10,6 +10,7 @@ These names are the only thing the reference repo pins about the two models (SUR
 from __future__ import annotations
 
 from collections import OrderedDict
+import math
 from typing import Dict, Tuple
 
 import torch
@@ -217,14 +218,22 @@ def param_count(manifest) -> int:
 # Seeded synthetic weights (N(0, 1/fan_in) conv/linear, norm affine (1,0), bias 0)
 # ----------------------------------------------------------------------------------------------
 def synth_state_dict(manifest, seed: int = 0, dtype=torch.float32, perturb: float = 0.0,
-                     gain: float = 1.0) -> Dict[str, torch.Tensor]:
+                     gain: float = 1.0, profile: str = "") -> Dict[str, torch.Tensor]:
     """Deterministic synthetic weights for a manifest.
 
     perturb=0 gives exactly the BASELINE.md §4 recipe.  perturb>0 additionally draws norm
     affines as (1 + p*N, p*N) and biases as p*N so that parity tests exercise every bias /
     affine path instead of multiplying by one and adding zero.
+
+    profile="heavy_tail": checkpoint-like dynamic range for the fp16 stress tests, since real weights
+    cannot be had offline -- 1 % of the output channels of every conv / linear behind a norm are outliers (rows x 30), biases ~ N(0, 0.5), norm gains log-uniform in [0.2, 3] with shifts ~ N(0, 0.5): activations are no longer O(1)
+    everywhere (group statistics dominated by single channels, residual streams in the hundreds, saturating softmax rows).
     """
     g = torch.Generator(device="cpu").manual_seed(seed)
+    heavy = profile.startswith("heavy_tail")
+    if profile and not heavy:
+        raise ValueError(f"unknown weight profile {profile!r}")
+    outlier = float(profile.split(":")[1]) if ":" in profile else 30.0        # "heavy_tail:<row scale>"
     sd: Dict[str, torch.Tensor] = {}
     for key, shape in manifest.items():
         is_norm = (".norm" in key or "group_norm" in key or "conv_norm_out" in key
@@ -232,17 +241,26 @@ def synth_state_dict(manifest, seed: int = 0, dtype=torch.float32, perturb: floa
         if len(shape) == 1:
             if key.endswith(".weight") and is_norm:
                 t = torch.ones(shape)
-                if perturb:
+                if heavy:
+                    t = torch.exp(torch.rand(shape, generator=g) * (math.log(3.0) - math.log(0.2)) + math.log(0.2))
+                elif perturb:
                     t = t + perturb * torch.randn(shape, generator=g)
             else:
                 t = torch.zeros(shape)
-                if perturb:
+                if heavy:
+                    t = 0.5 * torch.randn(shape, generator=g)
+                elif perturb:
                     t = perturb * torch.randn(shape, generator=g)
         else:
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
             t = torch.randn(shape, generator=g) * (gain / fan_in ** 0.5)
+            # (not on the layers that map a residual stream onto itself without a norm in front -- shortcuts, up / down
+            # samplers: outliers there compound multiplicatively, 30^7 over the up path, which no trained network does)
+            if heavy and shape[0] >= 100 and not any(t_ in key for t_ in ("conv_shortcut", "upsamplers", "downsamplers")):
+                rows = torch.randperm(shape[0], generator=g)[: max(1, shape[0] // 100)]
+                t[rows] *= outlier
         sd[key] = t.to(dtype)
     return sd
 

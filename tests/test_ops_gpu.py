@@ -392,6 +392,45 @@ def test_weight_stationary_gemm(engine_lib, case):
     assert rel_l2(y, ref) < 2e-3
 
 
+def test_wsgemm_residual_loads_need_no_range_check(engine_lib, monkeypatch):
+    """Round 2 saw HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in wsgemm_kernel<160, false, false, true, false> while its
+    residual prefetch was an inline-asm global_load; the range-checked raw_buffer_load that replaced it could have been
+    hiding a prefetch past the last row of a run.  It is not: with the residual's descriptor opened up
+    (no range check: an over-run would read whatever lies behind the tensor -- a NaN guard here) the outputs are bit for
+    bit those of the checked run, on the shape that faulted (8 x 64 x 64, 320 -> 320, 256 blocks x 4 runs) and on ragged
+    run lengths.  (tests/test_wsgemm_indexing.py walks the same index arithmetic on the host.)"""
+    for (N, H, W, Cout) in [(8, 64, 64, 320), (3, 64, 64, 320), (2, 64, 64, 640), (5, 64, 48, 960)]:
+        Cin = 320
+        M = N * H * W
+        g = torch.Generator().manual_seed(Cout + N)
+        x = torch.randn(M, Cin, generator=g).half().cuda()
+        w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).half().cuda()
+        b = torch.randn(Cout, generator=g).cuda()
+        guard = torch.full((M + 4096, Cout), float("nan"), dtype=torch.float16, device="cuda")
+        guard[:M] = torch.randn(M, Cout, generator=g).half().cuda()
+        r = guard[:M]
+        outs = []
+        for unchecked in (False, True):
+            if unchecked:
+                monkeypatch.setenv("SD_WS_RES_UNCHECKED", "1")
+            else:
+                monkeypatch.delenv("SD_WS_RES_UNCHECKED", raising=False)
+            y = torch.zeros(M, Cout, dtype=torch.float16, device="cuda")
+            engine_lib.sd_igemm_force(13, 1)
+            try:
+                rc = engine_lib.sd_op_conv2d(P(x), P(w), P(b), None, P(r), P(y), N, H, W, Cin, Cout, 1, 1, 0, 0, stream())
+            finally:
+                engine_lib.sd_igemm_force(-1, 0)
+            assert rc == 0, engine_lib.sd_last_error()
+            torch.cuda.synchronize()
+            outs.append(y)
+        monkeypatch.delenv("SD_WS_RES_UNCHECKED", raising=False)
+        assert torch.isfinite(outs[1].float()).all()
+        assert torch.equal(outs[0], outs[1])
+        ref = (F.linear(x.float(), w.float().view(Cout, Cin), b).half().float() + r.float())
+        assert rel_l2(outs[1], ref) < 2e-3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,flip,shift", [(320, 1, 0.0), (256, 1, 0.0), (320, 0, 1.0), (64, 0, 0.0)])
 def test_timestep_sinusoid(engine_lib, dim, flip, shift):
