@@ -150,6 +150,12 @@ int sd_vae_decode(sd_vae* v, const void* z, void* img, int B, int h, int w, void
 /* AutoencoderKL.encode(x) up to the moments (sd_unified_pipeline.py:1027-1032):
  * img [B,3,H,W] f16 -> moments [B,8,H/8,W/8] f16 (mean | logvar); sampling stays host code. */
 int sd_vae_encode(sd_vae* v, const void* img, void* moments, int B, int H, int W, void* stream);
+/* `vae.config.force_upcast` (sd_unified_pipeline.py:1020-1036): the reference runs such a VAE (SDXL's) in float32 around
+ * encode because its activations leave fp16's range.  The engine instead stores every inter-layer activation of the encoder
+ * 2^-shift times smaller -- GroupNorm is invariant to the scale of its input (eps is scaled along), so the encoder computes
+ * the same function with fp32 accumulators and statistics as before; shift = 0 (default) is plain fp16 storage.  Applies
+ * to the following sd_vae_encode calls of this handle. */
+int sd_vae_encode_range_shift(sd_vae* v, int shift);
 int sd_vae_memory(const sd_vae* v, int64_t* weight_bytes, int64_t* workspace_bytes);
 
 /* -- CLIP text encoder: replaces SDModelWrapper.text_encoder / .text_encoder_2 as encode_prompt calls

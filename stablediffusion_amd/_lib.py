@@ -96,6 +96,7 @@ SIGNATURES = {
     "sd_vae_finalize": (_I, [_P]),
     "sd_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sd_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sd_vae_encode_range_shift": (_I, [_P, _I]),
     "sd_vae_memory": (_I, [_P, C.POINTER(_I64), C.POINTER(_I64)]),
     "sd_clip_create": (_I, [C.POINTER(SdClipConfig), C.POINTER(_P)]),
     "sd_clip_destroy": (_I, [_P]),

@@ -141,6 +141,11 @@ int sd_vae_encode(sd_vae* v, const void* img, void* moments, int B, int H, int W
     return v->impl.encode(static_cast<const half_t*>(img), static_cast<half_t*>(moments), B, H, W,
                           static_cast<hipStream_t>(stream));
 }
+int sd_vae_encode_range_shift(sd_vae* v, int shift) {
+    if (!v || shift < 0 || shift > 14) { set_error("sd_vae_encode_range_shift: shift in 0..14"); return SD_ERR_INVALID; }
+    v->impl.encode_shift = shift;
+    return SD_OK;
+}
 int sd_vae_memory(const sd_vae* v, int64_t* weight_bytes, int64_t* workspace_bytes) {
     if (!v) { set_error("null handle"); return SD_ERR_INVALID; }
     if (weight_bytes) *weight_bytes = v->impl.ws.packed_bytes();

@@ -77,6 +77,8 @@ struct ConvFuse {
     int gn_in_groups = 0;
     float gn_in_eps = 0.f;
     int gn_in_silu = 0;
+    // y = acc_scale * (x W^T) + bias_scale * bias + ...: the range-scaled VAE encoder (powers of two; VAE::run_encode)
+    float acc_scale = 1.f, bias_scale = 1.f;
 };
 struct NormW {
     float* gamma = nullptr;

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
     f4 bias4[TN], wsum4[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-        bias4[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        bias4[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) * p.bias_scale : f4{0.f, 0.f, 0.f, 0.f};
     if (p.ln_stat) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) wsum4[j] = *reinterpret_cast<const f4*>(p.ln_wsum + n0 + wn * WTN + j * 16 + fq * 4);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm2_kernel(IGemmPar
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * WTN + j * 16 + fq * 4;
-            f4 v = acc[i][j] + add[j];
+            f4 v = acc[i][j] * p.acc_scale + add[j];
             if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
@@ -529,9 +529,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(IGemmParams p, con
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.acc_scale;
         if (p.bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e] * p.bias_scale;
         }
         if (p.rowadd) {
             const float* ra = p.rowadd + (m / OHW) * p.rowadd_ld + n;
@@ -582,9 +584,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_gs_kernel(IGemmParams p, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[e + 4] += b1[e]; }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.acc_scale;
         if (p.bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e] * p.bias_scale;
         }
         if (p.rowadd) {
             const float* ra = p.rowadd + (m / OHW) * p.rowadd_ld + n;
@@ -1007,7 +1011,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
         f4 add[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            add[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) : f4{0.f, 0.f, 0.f, 0.f};
+            add[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) * p.bias_scale : f4{0.f, 0.f, 0.f, 0.f};
         if (p.rowadd) {          // one image per tile: the row add is the same for every row
             const float* ra = p.rowadd + (long)img * p.rowadd_ld + n0 + wn * WTN + fq * 4;
             f4 r4[TN];
@@ -1023,7 +1027,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = wn * WTN + j * 16 + fq * 4;
-                const f4 v = acc[i][j] + add[j];
+                const f4 v = acc[i][j] * p.acc_scale + add[j];
                 h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
             }
@@ -1237,6 +1241,13 @@ static void igemm2_pick_raw(const IGemmParams& p, int* variant, int* splits);
 static bool wsgemm_enabled() {
     static const bool off = getenv("SD_NO_WSGEMM") != nullptr;
     return !off;
+}
+
+bool igemm2_scales_ok(const IGemmParams& p) {
+    if (!igemm2_supported(p) || p.geglu) return false;
+    int v, sp;
+    igemm2_pick(p, &v, &sp);
+    return v != 13 && v != 14;
 }
 
 bool igemm2_gn_fusable(const IGemmParams& p, int groups) {

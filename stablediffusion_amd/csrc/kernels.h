@@ -62,9 +62,14 @@ struct IGemmParams {
     int gni_silu = 0;
     const float* gni_gb = nullptr;
     int dbg_unchecked = 0;          // tests: wsgemm's residual descriptor without its range check
+    // ---- y = acc_scale * (x W^T) + bias_scale * bias (+ rowadd + res): the VAE encoder's range-scaled form (LDS-DMA
+    //      kernels and their split-K reductions; igemm2_scales_ok).  Scales are powers of two.  See VAE::run_encode. ----
+    float acc_scale = 1.f, bias_scale = 1.f;
 };
 // Whether launch_igemm2 can apply a GroupNorm of `groups` groups to this problem's input (p.gni_* set by the caller).
 bool igemm2_gn_fusable(const IGemmParams& p, int groups);
+// Whether launch_igemm2 honours acc_scale / bias_scale for this problem (not the GEGLU / weight-stationary forms)
+bool igemm2_scales_ok(const IGemmParams& p);
 // Whether launch_igemm2 will honour p.gnstat_out for `groups` groups; *rows = pixels per tile (GnStats::rows).
 bool igemm2_emits_gnstats(const IGemmParams& p, int groups, int* rows);
 // Whether launch_igemm2 will honour p.rowstat_out for this problem (LDS-DMA kernel, no split-K); when not,

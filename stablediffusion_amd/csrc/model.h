@@ -34,8 +34,13 @@ struct VaeAttn {
 
 // x_stats: GroupNorm summaries of x left by the convolution that produced it (or nullptr);
 // *out_stats: where the block leaves the summaries of `out` for the GroupNorm that consumes it next.
+// stream_scale s (a power of two, the VAE encoder's range-scaled form): x and out hold s times the block's true input /
+// output.  GroupNorm is invariant to the scale of its input up to eps, so norm1 / norm2 run with eps * s^2, conv1 /
+// conv2 emit s * (conv + bias), the shortcut (whose input carries s already) only scales its bias: the block computes the
+// same function, with every stored activation s times smaller.
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
-                const float* tproj, int tproj_ld, const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr);
+                const float* tproj, int tproj_ld, const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr,
+                float stream_scale = 1.f);
 void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L,
                  const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr);
 
@@ -102,6 +107,10 @@ struct VAE {
     int finalize();
     int decode(const half_t* z, half_t* img, int B, int h, int w, hipStream_t stream);
     int encode(const half_t* img, half_t* moments, int B, int H, int W, hipStream_t stream);
+    // The encoder with every inter-layer activation stored 2^-k times smaller (same function: see run_resnet): the
+    // engine's answer to `config.force_upcast` (sd_unified_pipeline.py:1020-1036 runs such VAEs in fp32 around encode
+    // because their activations leave fp16's range).  0 = plain fp16 storage.
+    int encode_shift = 0;
 
     sd_vae_config cfg;
     WeightStore ws;
@@ -131,9 +140,9 @@ struct VAE {
     int pack_attn(const std::string& p, VaeAttn* a);
     int pack_pointwise(const std::string& p, half_t** w, float** b);
     void run_attn(Ctx& c, const VaeAttn& a, View x, int N, int H, int W, View out, const GnStatBuf* x_stats,
-                  GnStatBuf** out_stats);
+                  GnStatBuf** out_stats, float stream_scale = 1.f);
     int run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w);
-    int run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W);
+    int run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W, float stream_scale);
 };
 
 // CLIP text encoder (transformers CLIPTextModel / CLIPTextModelWithProjection): the text side of

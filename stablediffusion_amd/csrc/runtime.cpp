@@ -369,6 +369,10 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
         p.gni_gb = fuse->gn_in->gb;
         if (c.dry) p.gni_part = reinterpret_cast<const float*>(8);      // planning pass: only "is set" matters (tile choice)
     }
+    if (fuse && (fuse->acc_scale != 1.f || fuse->bias_scale != 1.f)) {
+        p.acc_scale = fuse->acc_scale; p.bias_scale = fuse->bias_scale;
+        if (!igemm2_scales_ok(p)) { set_error("op_conv: output scaling needs the LDS-DMA kernels (not GEGLU / weight-stationary)"); c.err = 1; return; }
+    }
     const bool v2 = igemm2_supported(p);
     if (ln_in && !v2) { set_error("op_conv: the LayerNorm fold needs the LDS-DMA kernel"); c.err = 1; return; }
     if (gn_out) {

@@ -254,10 +254,11 @@ int UNet::finalize() {
 
 // ------------------------------------------------------------------------------------------ blocks
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
-                const float* tproj, int tproj_ld, const GnStatBuf* x_stats, GnStatBuf** out_stats) {
+                const float* tproj, int tproj_ld, const GnStatBuf* x_stats, GnStatBuf** out_stats, float stream_scale) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const long M = (long)N * H * W;
+    const float s = stream_scale, eps_s = eps * s * s;
     View h2(a.alloc_h(M * r.cout), r.cout, r.cout);
     // Both GroupNorm + SiLU pairs run inside the convolution that consumes them where the launch allows (op_gn_conv);
     // conv1's epilogue leaves the GroupNorm summaries of h2 for norm2, conv2's those of `out` for whoever normalises it.
@@ -265,16 +266,20 @@ void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, 
     ConvFuse f1;
     f1.gn_out = gn_wants_stats(HW, r.cout, G) ? ctx_gnbuf(c) : nullptr;
     f1.gn_groups = G;
-    op_gn_conv(c, r.n1, r.c1, x, N, H, W, h2, G, eps, 1, x_stats, tproj ? tproj + r.temb_off : nullptr, tproj_ld, nullptr, &f1);
+    f1.acc_scale = s; f1.bias_scale = s;
+    op_gn_conv(c, r.n1, r.c1, x, N, H, W, h2, G, eps_s, 1, x_stats, tproj ? tproj + r.temb_off : nullptr, tproj_ld, nullptr, &f1);
     View res = x;
     if (r.has_sc) {
         res = View(a.alloc_h(M * r.cout), r.cout, r.cout);
-        op_conv(c, r.sc, x, N, H, W, res);
+        ConvFuse fs;
+        fs.bias_scale = s;                       // (its input carries the stream's scale already)
+        op_conv(c, r.sc, x, N, H, W, res, 1, 0, nullptr, 0, nullptr, 0, -1, 0, s != 1.f ? &fs : nullptr);
     }
     ConvFuse f2;
     f2.gn_out = (out_stats && gn_wants_stats(HW, r.cout, G)) ? ctx_gnbuf(c) : nullptr;
     f2.gn_groups = G;
-    op_gn_conv(c, r.n2, r.c2, h2, N, H, W, out, G, eps, 1, f1.gn_out, nullptr, 0, &res, &f2);
+    f2.acc_scale = s; f2.bias_scale = s;
+    op_gn_conv(c, r.n2, r.c2, h2, N, H, W, out, G, eps_s, 1, f1.gn_out, nullptr, 0, &res, &f2);
     if (out_stats) *out_stats = f2.gn_out;
     a.release(mk);
 }

@@ -6,6 +6,7 @@
 // mid attention = one head over all channels with biased q/k/v.  Runs NHWC fp16 with the nearest-2x
 // upsample folded into the following conv's gather (no upsampled tensor is ever written).
 #include "model.h"
+#include <cmath>
 
 namespace sd {
 
@@ -158,13 +159,13 @@ int VAE::finalize() {
 }
 
 void VAE::run_attn(Ctx& c, const VaeAttn& at, View x, int N, int H, int W, View out, const GnStatBuf* x_stats,
-                   GnStatBuf** out_stats) {
+                   GnStatBuf** out_stats, float stream_scale) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const int C = at.C;
     const long M = (long)N * H * W;
     View hn(a.alloc_h(M * C), C, C);
-    op_groupnorm(c, at.gn, x, hn, N, (long)H * W, cfg.norm_num_groups, kVaeEps, 0, x_stats);
+    op_groupnorm(c, at.gn, x, hn, N, (long)H * W, cfg.norm_num_groups, kVaeEps * stream_scale * stream_scale, 0, x_stats);
     View qkv(a.alloc_h(M * 3 * C), 3 * C, 3 * C);
     op_conv(c, at.qkv, hn, N, H, W, qkv);
     View o(a.alloc_h(M * C), C, C);
@@ -172,6 +173,7 @@ void VAE::run_attn(Ctx& c, const VaeAttn& at, View x, int N, int H, int W, View 
     ConvFuse fo;
     fo.gn_out = (out_stats && gn_wants_stats((long)H * W, C, cfg.norm_num_groups)) ? ctx_gnbuf(c) : nullptr;
     fo.gn_groups = cfg.norm_num_groups;
+    fo.acc_scale = stream_scale; fo.bias_scale = stream_scale;      // the projection's output joins the (scaled) residual stream
     op_conv(c, at.out, o, N, H, W, out, 1, 0, nullptr, 0, &x, 0, -1, 0, &fo);
     if (out_stats) *out_stats = fo.gn_out;
     a.release(mk);
@@ -256,7 +258,11 @@ int VAE::run_decode(Ctx& c, const half_t* z, half_t* img, int B, int h, int w) {
     return c.err;
 }
 
-int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W) {
+// stream_scale s = 2^-encode_shift: every activation between conv_in and conv_norm_out is stored s times its true value
+// (conv_in and the convolutions that write the residual stream emit s * (conv + bias); those that read it -- shortcuts,
+// downsamplers -- scale only their bias; every GroupNorm runs with eps * s^2).  The function computed is the same.
+int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, int W, float stream_scale) {
+    const float ss = stream_scale;
     Arena& a = *c.arena;
     const int nb = cfg.num_blocks;
     const int* boc = cfg.block_out_channels;
@@ -280,6 +286,7 @@ int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, in
         ConvW pw = e_conv_in; pw.ks = 1;
         ConvFuse f;
         gn_fuse(f, (long)h * w, boc[0]);
+        f.acc_scale = ss; f.bias_scale = ss;
         op_conv(c, pw, View(col, e_conv_in.K, (int)e_conv_in.K), B, h, w, cur, 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
         xs = f.gn_out;
         a.release(mk);
@@ -288,7 +295,7 @@ int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, in
         for (int j = 0; j < cfg.layers_per_block; ++j) {
             const Resnet& r = e_down[i][j];
             View nxt(a.alloc_h(M * r.cout), r.cout, r.cout);
-            run_resnet(c, r, cur, B, h, w, nxt, G, kVaeEps, nullptr, 0, xs, &xs);
+            run_resnet(c, r, cur, B, h, w, nxt, G, kVaeEps, nullptr, 0, xs, &xs, ss);
             cur = nxt;
         }
         if (i != nb - 1) {
@@ -296,6 +303,7 @@ int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, in
             View nxt(a.alloc_h(M / 4 * C), C, C);
             ConvFuse f;
             gn_fuse(f, (long)(h / 2) * (w / 2), C);
+            f.bias_scale = ss;                   // (reads the scaled stream)
             op_conv(c, e_ds[i], cur, B, h, w, nxt, 2, 0, nullptr, 0, nullptr, 0, /*pad=*/0, 0, &f);
             xs = f.gn_out;
             h /= 2; w /= 2; M /= 4;
@@ -304,10 +312,10 @@ int VAE::run_encode(Ctx& c, const half_t* img, half_t* moments, int B, int H, in
     }
     const int top = boc[nb - 1];
     View t0(a.alloc_h(M * top), top, top), t1(a.alloc_h(M * top), top, top);
-    run_resnet(c, e_mid0, cur, B, h, w, t0, G, kVaeEps, nullptr, 0, xs, &xs);
-    run_attn(c, e_attn, t0, B, h, w, t1, xs, &xs);
-    run_resnet(c, e_mid1, t1, B, h, w, t0, G, kVaeEps, nullptr, 0, xs, &xs);
-    op_groupnorm(c, e_norm_out, t0, t1, B, (long)h * w, G, kVaeEps, 1, xs);
+    run_resnet(c, e_mid0, cur, B, h, w, t0, G, kVaeEps, nullptr, 0, xs, &xs, ss);
+    run_attn(c, e_attn, t0, B, h, w, t1, xs, &xs, ss);
+    run_resnet(c, e_mid1, t1, B, h, w, t0, G, kVaeEps, nullptr, 0, xs, &xs, ss);
+    op_groupnorm(c, e_norm_out, t0, t1, B, (long)h * w, G, kVaeEps * ss * ss, 1, xs);
     View o(a.alloc_h(M * lc2), lc2, lc2);
     op_conv(c, e_conv_out, t1, B, h, w, o);
     half_t* o_nchw = a.alloc_h(M * lc2);
@@ -346,7 +354,7 @@ int VAE::encode(const half_t* img, half_t* moments, int B, int H, int W, hipStre
     if (key != planned_key) {
         Ctx dry{&arena, stream, true};
         arena.begin(true);
-        int rc = run_encode(dry, img, moments, B, H, W);
+        int rc = run_encode(dry, img, moments, B, H, W, ldexpf(1.f, -encode_shift));
         if (rc) return rc;
         if (arena.peak() > arena.capacity()) {
             SD_HIP_CHECK(hipDeviceSynchronize());
@@ -356,7 +364,7 @@ int VAE::encode(const half_t* img, half_t* moments, int B, int H, int W, hipStre
     }
     Ctx ctx{&arena, stream, false};
     arena.begin(false);
-    int rc = run_encode(ctx, img, moments, B, H, W);
+    int rc = run_encode(ctx, img, moments, B, H, W, ldexpf(1.f, -encode_shift));
     if (!rc && arena.overflow()) { set_error("vae: workspace overflow (planner bug)"); return 2; }
     return rc;
 }

@@ -251,6 +251,7 @@ class HipAutoencoderKL:
         _lib.check(self._lib.sd_vae_create(C.byref(c), C.byref(self._h)), "sd_vae_create")
         self.config = _Config(**config.to_dict())
         self._finalized = False
+        self._enc_shift = 0           # sd_vae_encode_range_shift in effect (force_upcast VAEs: raised on overflow)
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         _lib.require_gpu()
@@ -267,9 +268,9 @@ class HipAutoencoderKL:
 
     def to(self, device=None, dtype=None):
         # the reference flips the VAE to fp32 around encode when force_upcast is set
-        # (sd_unified_pipeline.py:1020-1036); the engine keeps fp32 accumulators and statistics but fp16
-        # activations, so dtype requests are accepted and ignored, and encode_moments raises if a
-        # force_upcast VAE really overflows (see there).
+        # (sd_unified_pipeline.py:1020-1036); the engine keeps fp32 accumulators and statistics and fp16
+        # activations, so dtype requests are accepted and ignored; a force_upcast VAE whose activations leave
+        # fp16's range is re-run range-shifted by encode_moments (see there).
         if device is not None and not isinstance(device, torch.dtype) and torch.device(device).type != "cuda":
             raise _lib.EngineError("HipAutoencoderKL lives on the HIP device only")
         return self
@@ -305,12 +306,25 @@ class HipAutoencoderKL:
                                          C.c_void_p(_stream_ptr()))
         _lib.check(rc, "sd_vae_encode")
         if getattr(self.cfg, "force_upcast", False) and not bool(torch.isfinite(mom).all()):
-            # The reference runs the VAE in fp32 around encode when force_upcast is set
-            # (sd_unified_pipeline.py:1020-1036: the SDXL VAE overflows fp16 activations on some images).  The
-            # engine keeps fp32 accumulators and statistics but stores inter-layer activations in fp16: an
-            # overflow is reported, never passed on as inf / NaN latents (INTEGRATION.md "limits").
-            raise _lib.EngineError("VAE encode overflowed the engine's fp16 activations (config.force_upcast is set: "
-                                   "this VAE needs fp32 activations for this image); no latents were produced")
+            # The reference runs the VAE in fp32 around encode when force_upcast is set (sd_unified_pipeline.py:1020-1036:
+            # the SDXL VAE's activations leave fp16's range on some images).  The engine's equivalent: the same encoder
+            # with every inter-layer activation stored 2^-k times smaller (GroupNorm is scale-invariant, eps scaled
+            # along: sd_vae_encode_range_shift), k raised until the moments are finite and kept for the handle's next
+            # calls.  fp32 accumulators and statistics as always; nothing overflows silently.
+            for shift in (4, 8, 12):
+                if shift <= self._enc_shift:
+                    continue
+                _lib.check(self._lib.sd_vae_encode_range_shift(self._h, shift), "sd_vae_encode_range_shift")
+                self._enc_shift = shift
+                with torch.cuda.device(self.device):
+                    rc = self._lib.sd_vae_encode(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(mom.data_ptr()), B, H, W,
+                                                 C.c_void_p(_stream_ptr()))
+                _lib.check(rc, "sd_vae_encode")
+                if bool(torch.isfinite(mom).all()):
+                    break
+            else:
+                raise _lib.EngineError("VAE encode left fp16's range even with its activations stored 2^-12 times smaller "
+                                       "(config.force_upcast is set); no latents were produced")
         return mom
 
     def encode(self, x, return_dict=True):

@@ -382,3 +382,34 @@ def test_sd15_unet_at_128x128_latents(engine_lib):
     ref = oracle_unet_on_gpu(cfg, sd, x, torch.tensor(261.0), ehs)
     assert torch.isfinite(got.float()).all()
     assert rel_l2(got, ref) < TOL
+
+
+def test_force_upcast_vae_encode_beyond_fp16_range(engine_lib):
+    """`config.force_upcast` (sd_unified_pipeline.py:1020-1036: the reference runs SDXL's VAE in fp32 around encode because
+    its activations leave fp16's range).  An SDXL-configured encoder whose first convolution is scaled until plain fp16
+    storage overflows (residual stream ~ 2e5 > 65504): the engine re-runs it with its activations stored 2^-k times
+    smaller (GroupNorm is scale-invariant; sd_vae_encode_range_shift) and has to match the fp32 oracle, which never
+    notices the scale.  Round 2 raised EngineError here."""
+    cfg = config.sdxl_vae()
+    assert cfg.force_upcast
+    sd = weights.synth_state_dict(weights.vae_manifest(cfg), seed=61, dtype=torch.float16, perturb=0.1)
+    sd["encoder.conv_in.weight"] = (sd["encoder.conv_in.weight"].float() * 2.0e4).half()     # |conv_in(x)| ~ 1e5
+    sd["encoder.conv_in.bias"] = (sd["encoder.conv_in.bias"].float() * 2.0e4).half()
+    vae = HipAutoencoderKL(cfg).load_state_dict(sd)
+    g = torch.Generator().manual_seed(9)
+    img = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).half()
+    with torch.no_grad(), _ActivationLog(unet_ref, vae_ref) as log:
+        ref = vae_ref.vae_encode_moments(cfg, {k: v.float().cuda() for k, v in sd.items()}, img.float().cuda())
+    peak = log.report("SDXL-config VAE encoder, conv_in x 2e4")
+    assert peak > 65504.0, "the case must really leave fp16's range"
+    got = vae.encode_moments(img.cuda())
+    assert vae._enc_shift > 0 and torch.isfinite(got.float()).all()
+    err = rel_l2(got[:, :4], ref[:, :4])
+    print(f"    activations stored 2^-{vae._enc_shift} times smaller: means rel-L2 vs the fp32 oracle {err:.2e}")
+    assert err < TOL
+    # an ordinary image on the same handle keeps working at the raised shift (precision unchanged: powers of two)
+    plain = HipAutoencoderKL(cfg).load_state_dict(weights.synth_state_dict(weights.vae_manifest(cfg), seed=61, dtype=torch.float16, perturb=0.1))
+    a = plain.encode_moments(img.cuda())
+    engine_lib.sd_vae_encode_range_shift(plain._h, 8)
+    b = plain.encode_moments(img.cuda())
+    assert plain._enc_shift == 0 and rel_l2(b[:, :4], a[:, :4]) < 2e-3
