@@ -1007,11 +1007,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
 
     // ---- fused epilogue through LDS (as igemm2_kernel: loads batched ahead of their use) ----
     __syncthreads();
+    // (the two scales are read from the kernel arguments HERE, through volatile loads: as ordinary uses of `p` they are
+    // fetched at kernel entry and held in scalar registers across the main loop, which the unrolled 160-column form paid
+    // for with 16 more spilled registers, some reloaded inside the loop -- tools/check_spills.py)
+    const float acc_scale = *reinterpret_cast<const volatile float*>(&p.acc_scale);
+    const float bias_scale = *reinterpret_cast<const volatile float*>(&p.bias_scale);
     {
         f4 add[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            add[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) * p.bias_scale : f4{0.f, 0.f, 0.f, 0.f};
+            add[j] = p.bias ? *reinterpret_cast<const f4*>(p.bias + n0 + wn * WTN + j * 16 + fq * 4) * bias_scale : f4{0.f, 0.f, 0.f, 0.f};
         if (p.rowadd) {          // one image per tile: the row add is the same for every row
             const float* ra = p.rowadd + (long)img * p.rowadd_ld + n0 + wn * WTN + fq * 4;
             f4 r4[TN];
@@ -1027,7 +1032,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(IGemmParams p, float*
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = wn * WTN + j * 16 + fq * 4;
-                const f4 v = acc[i][j] * p.acc_scale + add[j];
+                const f4 v = acc[i][j] * acc_scale + add[j];
                 h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<h4*>(sC + pr * LDC + col) = o;
             }

@@ -37,6 +37,10 @@ CONV_CASES = [
     (1, 8, 8, 1280, 1280, 3, 1, 0, True),      # small M, long K
     (1, 16, 16, 64, 4, 3, 1, 0, False),        # conv_out: Cout = 4 (scalar epilogue)
     (1, 16, 16, 64, 3, 3, 1, 0, False),        # VAE conv_out: Cout = 3
+    (8, 8, 8, 1280, 1280, 3, 1, 0, True),      # 8 x 8 level of the C2 UNet: halo kernel, four whole images per tile, split over the slabs
+    (4, 8, 8, 128, 320, 3, 1, 0, True),        # one tile of four images, no split (two slabs): fused epilogue with per-image row add
+    (4, 8, 16, 192, 128, 3, 1, 0, True),       # 8 x 16 maps: two images per tile, 128-column form
+    (8, 8, 8, 2560, 1280, 3, 1, 0, False),     # concat width of the up path at 8 x 8
 ]
 
 
