@@ -1381,6 +1381,9 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
     int v, sp;
     igemm2_pick(p, &v, &sp);
     if (sp > 1 && !partial) sp = 1;
+    static const bool pg_k320 = getenv("SD_PGEMM_K320") != nullptr;       // A/B: the K = 320 GEGLU on it instead of wsgemm
+    if (p.geglu && ((v != 13 && v != 14) || pg_k320) && g_force_variant.load() < 0 && pgemm_geglu_supported(p))
+        return launch_pgemm_geglu(p, s);
     switch (v) {
         case 0: return launch_v2<256, 128, 4, 2, 3>(p, partial, sp, s);
         case 1: return launch_v2<128, 128, 2, 2, 2>(p, partial, sp, s);

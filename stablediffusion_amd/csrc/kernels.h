@@ -91,6 +91,10 @@ constexpr int kWeightRowPad = 256;
 bool wsgemm_supported(const IGemmParams& p);
 int wsgemm_rowstat_parts(const IGemmParams& p);         // column partials per row it writes to rowstat_out
 int launch_wsgemm(const IGemmParams& p, hipStream_t s);
+// Persistent GEGLU projection for the K >= 128 pointwise problems with >= 512 tiles of 256 x 128 (pgemm.hip): one block
+// per CU owns an M tile and a run of N tiles, its LDS-DMA ring runs across the tile boundaries; launch_igemm2 routes to it.
+bool pgemm_geglu_supported(const IGemmParams& p);
+int launch_pgemm_geglu(const IGemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // Normalisation (norm.hip)

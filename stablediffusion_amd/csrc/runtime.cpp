@@ -413,12 +413,14 @@ void op_conv(Ctx& c, const ConvW& w, View x, int N, int H, int W, View y, int st
             // split-K launches keep the kernel's name: their bracket also covers the small
             // splitk_epilogue_kernel, so the reported rate is slightly pessimistic for them
             snprintf(nbuf, sizeof(nbuf), igemm2_name(var), pw ? "true" : "false");
+            const bool pg = p.geglu && var != 13 && var != 14 && pgemm_geglu_supported(p);
+            if (pg) snprintf(nbuf, sizeof(nbuf), "geglu_persist_kernel");
             (void)fbuf;
             // SD_PROF_SHAPES=1 (tools/profile_layers.py): one row per (tile variant, split-K, problem shape,
             // fused extras) instead of one per kernel instantiation
             static const bool by_shape = getenv("SD_PROF_SHAPES") != nullptr;
             if (by_shape)
-                snprintf(nbuf, sizeof(nbuf), "v%d/k%d %dx%dx%d ks%d%s%s%s%s%s%s", var, sp, p.M, p.Cout, p.K, p.KS, res ? " res" : "",
+                snprintf(nbuf, sizeof(nbuf), "%s%d/k%d %dx%dx%d ks%d%s%s%s%s%s%s", pg ? "pg" : "v", var, sp, p.M, p.Cout, p.K, p.KS, res ? " res" : "",
                          geglu ? " geglu" : "", p.ln_stat ? " ln" : "", p.rowstat_out ? " rs" : "", p.gnstat_out ? " gs" : "",
                          p.gni_part ? " gn" : "");
             name = nbuf;

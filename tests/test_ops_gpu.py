@@ -132,6 +132,34 @@ def test_conv_geglu(engine_lib):
     assert rel_l2(y, ref) < 2e-3
 
 
+@pytest.mark.parametrize("M,C", [(8192, 640), (2048, 1280), (1024, 640), (2560, 384)])
+def test_geglu_persistent_projection(engine_lib, M, C):
+    """geglu_persist_kernel (pgemm.hip): the FeedForward GEGLU projection of the 32 x 32 / 16 x 16 levels as one
+    persistent block per CU whose DMA ring runs across tile boundaries -- the C2 shapes (5 and 2.5 tiles per block), a
+    run of exactly two tiles per block, and ragged runs (10 M tiles x 24 N tiles over 250 blocks), against
+    Linear -> chunk -> hidden * gelu(gate) in fp32.  (The LayerNorm-consumer form runs inside the UNet tests.)"""
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).half()
+    w = (torch.randn(8 * C, C, generator=g) / C ** 0.5).half()
+    b = torch.randn(8 * C, generator=g) * 0.2
+    xd, wd, bd = h(x), h(w), b.cuda()
+    proj = (xd.float() @ wd.float().t() + bd).half().float()
+    hid, gate = proj.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate)
+    y = torch.zeros(M, 4 * C, dtype=torch.float16, device="cuda")
+    rc = engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, None, P(y), 1, M, 1, C, 8 * C, 1, 1, 0, 1, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert rel_l2(y, ref) < 2e-3
+    # twice more on the same buffers: a race between the ring and a tile's reads would not repeat bit for bit
+    for _ in range(2):
+        y2 = torch.zeros_like(y)
+        engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, None, P(y2), 1, M, 1, C, 8 * C, 1, 1, 0, 1, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 256, 64, 1, 1e-5), (2, 1024, 320, 1, 1e-5),
                                              (1, 64, 1920, 1, 1e-5), (3, 100, 128, 0, 1e-6),
                                              (1, 4096, 2560, 1, 1e-5), (2, 33, 960, 0, 1e-6),
