@@ -53,8 +53,10 @@ __device__ __forceinline__ unsigned pack_rtz(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-template <int D, int QT, int KT, bool PRESC>
-__global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
+// NWV: waves per block (4 or 8).  Eight waves share one K / V tile stream: half the DMA pieces and barrier episodes per
+// query (the DMA issue was 18 % of the d = 40 kernel in the round-2 ablation), two waves per SIMD from ONE block.
+template <int D, int QT, int KT, bool PRESC, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void attn_kernel(const half_t* __restrict__ q,
                                                    const half_t* __restrict__ k,
                                                    const half_t* __restrict__ v,
                                                    half_t* __restrict__ out, int Tq, int Tk_all,
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     constexpr int NCH = KT * CH;                         // chunk slots per tile (K and V alike)
     constexpr bool ONES = DT * 16 > D;                   // spare PV rows -> denominator via MFMA
     constexpr bool PREFETCH = D <= 160;                  // register-staged prefetch of the next tile
-    constexpr int QB = 64 * QT;                          // queries per block
+    constexpr int QB = 16 * QT * NWV;                    // queries per block
+    constexpr int NTH = 64 * NWV;
 
     // With PREFETCH the K/V tiles are double-buffered in LDS (one barrier per tile); buffer b lives
     // at smem + b * TILE_HALVES.
@@ -111,13 +114,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 #pragma unroll
     for (int bufi = 0; bufi < (PREFETCH ? 2 : 1); ++bufi) {
         if constexpr (KPAD > 0) {
-            for (int idx = tid; idx < KT * KPAD; idx += 256) {
+            for (int idx = tid; idx < KT * KPAD; idx += NTH) {
                 const int r = idx / KPAD, c = D + idx - r * KPAD;
                 sK[bufi * TILE_HALVES + r * KSTR + c] = (half_t)0.f;
             }
         }
         if constexpr (VPAD > 0) {
-            for (int idx = tid; idx < KT * VPAD; idx += 256) {
+            for (int idx = tid; idx < KT * VPAD; idx += NTH) {
                 const int r = idx / VPAD, c = D + idx - r * VPAD;
                 sV[bufi * TILE_HALVES + r * VSTR + c] = (ONES && c == D) ? (half_t)1.f : (half_t)0.f;
             }
@@ -164,14 +167,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
     // The tile's SPRK + SPRV pieces are dealt round-robin over the four waves as ONE list (K pieces first):
     // with separate K and V lists wave 0 issued 4 of d = 40's 11 pieces and waves 2, 3 two each, and a
     // piece's issue (60-185 cycles, MI355X_MICROARCH.md) sits on the wave's critical path.
-    constexpr int NP = SPRK + SPRV, NPW = (NP + 3) / 4;
+    constexpr int NP = SPRK + SPRV, NPW = (NP + NWV - 1) / NWV;
     const int wavu = __builtin_amdgcn_readfirstlane(wave);
     __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(kb), 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(vb), 0, 0x7fffffff, 0x00020000);
     int p_row[NPW], p_off[NPW];                               // off < 0: pad chunk, lane sits out
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-        const int q = wavu + 4 * j;                           // wave-uniform piece id
+        const int q = wavu + NWV * j;                         // wave-uniform piece id
         const bool isk = q < SPRK;
         const int spr = isk ? SPRK : SPRV;
         const int p = (isk ? q : q - SPRK) * 64 + lane;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
         const int lim = Tk - kt0;                             // rows of this tile that exist
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            const int q = wavu + 4 * j;
+            const int q = wavu + NWV * j;
             if (q < NP && p_off[j] >= 0) {
                 const bool isk = q < SPRK;
                 const unsigned voff = p_row[j] < lim ? (isk ? kbase : vbase) + (unsigned)p_off[j] : kOOB;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
             if (kt0 + KT < Tk) issue_tile(cur ^ 1, kt0 + KT);
         } else {
             __syncthreads();                   // previous tile fully consumed (and padding written)
-            for (int idx = tid; idx < NCH; idx += 256) {
+            for (int idx = tid; idx < NCH; idx += NTH) {
                 const int r = idx / CH, c = (idx - r * CH) * 8;
                 h8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (kt0 + r < Tk) {
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const half_t* __restrict__ q,
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int D, int QT, int KT, bool PRESC>
+template <int D, int QT, int KT, bool PRESC, int NWV = 4>
 int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, int B, int Tq, int Tk,
                 int heads, long ldq, long ldk, long ldv, long ldo, int causal, bool q_has_scale, hipStream_t s) {
     constexpr int DK = (D + 31) / 32 * 32;
@@ -427,13 +430,13 @@ int launch_attn(const half_t* q, const half_t* k, const half_t* v, half_t* out, 
     constexpr size_t lds = (size_t)KT * (k_row_halves(D) * 2 + odd32_bytes(DT * 16 * 2)) * (D <= 160 ? 2 : 1);
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT, PRESC>),
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, QT, KT, PRESC, NWV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // q_has_scale with the general kernel: the scores only need the running-max subtraction
     const float scale_log2e = q_has_scale ? 1.0f : 1.4426950408889634f / sqrtf((float)D);
-    const int qblocks = cdiv(Tq, 64 * QT);
-    hipLaunchKernelGGL((attn_kernel<D, QT, KT, PRESC>), dim3(qblocks * B * heads), dim3(256), lds, s, q, k, v,
+    const int qblocks = cdiv(Tq, 16 * QT * NWV);
+    hipLaunchKernelGGL((attn_kernel<D, QT, KT, PRESC, NWV>), dim3(qblocks * B * heads), dim3(64 * NWV), lds, s, q, k, v,
                        out, Tq, Tk, heads, ldq, ldk, ldv, ldo, scale_log2e, causal, qblocks);
     SD_HIP_CHECK(hipGetLastError());
     return 0;
@@ -461,6 +464,10 @@ int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* 
     // pairs = 128 blocks of 128 queries for 256 CUs): halve the block there.  (d = 40 was also tried at 48 / 32 /
     // 16 queries per wave for more waves per SIMD: 299 -> 318 / 318 / 403 us on the 4096-token case: it is not
     // latency-bound.)
+    // eight waves per block where there are enough query blocks to fill the chip with them (SD_ATTN_NWV=4: A/B switch)
+    static const int nwv = getenv("SD_ATTN_NWV") ? atoi(getenv("SD_ATTN_NWV")) : 8;
+    if (d == 40 && prescaled && !causal && nwv == 8 && (long)cdiv(Tq, 512) * B * heads >= 512)
+        return launch_attn<40, 4, 64, true, 8>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, true, s);
     if (d == 160 && (long)cdiv(Tq, 128) * B * heads < 256)
         return launch_attn<160, 1, 64, false>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, prescaled != 0, s);
     switch (d) {

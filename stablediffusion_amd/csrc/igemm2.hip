@@ -1213,8 +1213,9 @@ static const char* kIgemm2Names[] = {
     "igemm2_kernel<128,64,2,2,3,%s,false,64>",  "igemm2_kernel<128,160,2,2,3,%s,false,64>",
     "conv3x3_halo_kernel<160>",
     "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>",
-    "wsgemm_kernel<160,false,...>", "wsgemm_kernel<128,true,...>", "conv3x3_halo_kernel<128>"};
-constexpr int kNumVariants = 16;
+    "wsgemm_kernel<160,false,...>", "wsgemm_kernel<128,true,...>", "conv3x3_halo_kernel<128>",
+    "igemm2_kernel<128,80,4,1,4,%s,false,64>", "igemm2_kernel<128,80,4,1,5,%s,false,64>"};
+constexpr int kNumVariants = 18;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -1227,7 +1228,8 @@ bool igemm2_supported(const IGemmParams& p) {
 
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
-                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}, {128, 80}, {128, 128}, {256, 128}};
+                                               {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}, {128, 80}, {128, 128}, {256, 128},
+                                               {128, 80}, {128, 80}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -1399,6 +1401,8 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 15: return launch_halo<128>(p, partial, sp, s);
         case 11: return launch_v2<128, 80, 4, 1, 2>(p, partial, sp, s);
         case 12: return launch_v2<128, 80, 4, 1, 3>(p, partial, sp, s);
+        case 16: return launch_v2<128, 80, 4, 1, 4>(p, partial, sp, s);
+        case 17: return launch_v2<128, 80, 4, 1, 5>(p, partial, sp, s);
         case 13:
         case 14: return launch_wsgemm(p, s);
         default: set_error("igemm2: bad variant"); return 1;
