@@ -127,7 +127,8 @@ def rocprof_avg_us_for(function: str):
     return round(tot / n / 1e3, 2) if n else None
 
 
-KERNEL_FAMILIES = (("conv/GEMM", ("igemm2_kernel", "conv3x3_halo_kernel", "igemm_kernel", "wsgemm_kernel")), ("attention", ("attn_kernel",)),
+KERNEL_FAMILIES = (("conv/GEMM", ("igemm2_kernel", "conv3x3_halo_kernel", "igemm_kernel", "wsgemm_kernel", "geglu_persist_kernel",
+                                  "ffn_fused_kernel")), ("attention", ("attn_kernel",)),
                    ("norms", ("groupnorm", "layernorm", "row_stats")))
 
 

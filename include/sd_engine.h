@@ -270,6 +270,16 @@ int sd_op_groupnorm_conv2d(const void* x_nhwc, const void* gamma, const void* be
                            const void* w_oihw, const void* bias, const void* rowadd, const void* res_nhwc, void* y_nhwc,
                            int N, int H, int W, int Cin, int Cout, int ksize, int iters, float* ms_per_launch, int* fused,
                            void* stream);
+/* The GEGLU feed-forward of BasicTransformerBlock with its norm and residual (diffusers attention.py: norm3 -> FeedForward
+ * (GEGLU) -> + hidden_states, under sd_unified_pipeline.py:475-482):
+ *   y = x + (h * gelu(g)) W2^T + b2,   [h | g] = LayerNorm(x; gamma, beta, eps) W1^T + b1
+ * x, y [M, C] f16; w1 [8C, C], w2 [C, 4C] f16 (PyTorch Linear layout); gamma, beta, b1 [8C], b2 [C] f32.  For C = 320 and
+ * M % 128 == 0 one launch keeps the 4C-wide hidden tensor on the CU (*fused = 1, ffn.hip); otherwise the projection with
+ * its GEGLU epilogue and the output linear with its residual epilogue run (*fused = 0).  iters > 0: ms_per_launch[0] = the
+ * path taken, ms_per_launch[1] = the two-GEMM form on the same operands (packing outside the timed launches). */
+int sd_op_ffn_geglu(const void* x, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* w1, const void* b1,
+                    const void* w2, const void* b2, void* y, int M, int C, int iters, float* ms_per_launch, int* fused,
+                    void* stream);
 /* Same operator, timed: `iters` back-to-back launches bracketed by HIP events on `stream`
  * (after two warm-up launches); used by tools/tune_igemm.py to pick tile variants per shape. */
 int sd_bench_conv2d(const void* x_nhwc, const void* w_oihw, void* y_nhwc, int N, int H, int W, int Cin,

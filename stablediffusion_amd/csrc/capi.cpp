@@ -494,6 +494,96 @@ int sd_op_groupnorm_conv2d(const void* x, const void* gamma_f32, const void* bet
                        iters > 0 ? iters : 1, iters > 0 ? ms_per_launch : nullptr, nullptr, &gh);
 }
 
+int sd_op_ffn_geglu(const void* x, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* w1, const void* b1,
+                    const void* w2, const void* b2, void* y, int M, int C, int iters, float* ms_per_launch, int* fused,
+                    void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!x || !ln_gamma || !ln_beta || !w1 || !b1 || !w2 || !b2 || !y || M < 1 || C % 64 != 0) { set_error("sd_op_ffn_geglu: bad arguments"); return SD_ERR_INVALID; }
+    const long H4 = 4L * C, O1 = 8L * C;
+    const long r1 = (O1 + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad, r2 = ((long)C + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    DevScope scope;
+    half_t *wg = nullptr, *w2p = nullptr, *hid = nullptr;
+    float *bg = nullptr, *nb = nullptr, *wsum = nullptr, *b2p = nullptr, *stat = nullptr;
+    SD_DEV_ALLOC(scope, wg, (size_t)r1 * C * 2);
+    SD_DEV_ALLOC(scope, bg, (size_t)r1 * 4);
+    SD_DEV_ALLOC(scope, nb, (size_t)r1 * 4);
+    SD_DEV_ALLOC(scope, wsum, (size_t)r1 * 4);
+    SD_DEV_ALLOC(scope, w2p, (size_t)r2 * H4 * 2);
+    SD_DEV_ALLOC(scope, b2p, (size_t)r2 * 4);
+    SD_DEV_ALLOC(scope, stat, (size_t)M * 2 * 4);
+    SD_HIP_CHECK(hipMemsetAsync(wg, 0, (size_t)r1 * C * 2, s));
+    SD_HIP_CHECK(hipMemsetAsync(bg, 0, (size_t)r1 * 4, s));
+    SD_HIP_CHECK(hipMemsetAsync(nb, 0, (size_t)r1 * 4, s));
+    SD_HIP_CHECK(hipMemsetAsync(wsum, 0, (size_t)r1 * 4, s));
+    SD_HIP_CHECK(hipMemsetAsync(w2p, 0, (size_t)r2 * H4 * 2, s));
+    SD_HIP_CHECK(hipMemsetAsync(b2p, 0, (size_t)r2 * 4, s));
+    // the GEGLU packing of WeightStore::pack_geglu: every 128-row group = 64 hidden rows, then their 64 gate rows
+    const half_t* w1h = static_cast<const half_t*>(w1);
+    const float* b1f = static_cast<const float*>(b1);
+    for (long blk = 0; blk < H4 / 64; ++blk) {
+        SD_HIP_CHECK(hipMemcpyAsync(wg + blk * 128 * C, w1h + blk * 64 * C, (size_t)64 * C * 2, hipMemcpyDeviceToDevice, s));
+        SD_HIP_CHECK(hipMemcpyAsync(wg + (blk * 128 + 64) * C, w1h + (H4 + blk * 64) * C, (size_t)64 * C * 2, hipMemcpyDeviceToDevice, s));
+        SD_HIP_CHECK(hipMemcpyAsync(bg + blk * 128, b1f + blk * 64, 64 * 4, hipMemcpyDeviceToDevice, s));
+        SD_HIP_CHECK(hipMemcpyAsync(bg + blk * 128 + 64, b1f + H4 + blk * 64, 64 * 4, hipMemcpyDeviceToDevice, s));
+    }
+    SD_HIP_CHECK(hipMemcpyAsync(w2p, w2, (size_t)C * H4 * 2, hipMemcpyDeviceToDevice, s));
+    SD_HIP_CHECK(hipMemcpyAsync(b2p, b2, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    int rc = launch_ln_fold(wg, C, (int)O1, static_cast<const float*>(ln_gamma), static_cast<const float*>(ln_beta), bg, nb, wsum, 0, 1.0f, s);
+    if (!rc) rc = launch_row_stats(static_cast<const half_t*>(x), C, stat, M, C, s);
+    if (rc) return rc;
+    FfnParams p;
+    p.x = static_cast<const half_t*>(x); p.ldx = C; p.y = static_cast<half_t*>(y); p.ldy = C;
+    p.w1 = wg; p.b1 = nb; p.wsum1 = wsum; p.w1_rows = (int)r1;
+    p.w2 = w2p; p.b2 = b2p; p.w2_rows = (int)r2;
+    p.ln_stat = stat; p.ln_parts = 1; p.ln_eps = ln_eps;
+    p.M = M; p.C = C; p.hidden = (int)H4;
+    const bool use_fused = ffn_fused_supported(p);
+    if (fused) *fused = use_fused ? 1 : 0;
+    IGemmParams g1{}, g2{};                // the two-GEMM form: projection with its GEGLU epilogue, output linear with its residual
+    if (!use_fused || ms_per_launch) SD_DEV_ALLOC(scope, hid, (size_t)M * H4 * 2);
+    g1.x = p.x; g1.ldx = C; g1.w = wg; g1.bias = nb; g1.y = hid; g1.ldy = H4; g1.N = 1; g1.H = M; g1.W = 1; g1.Cin = C; g1.OH = M; g1.OW = 1;
+    g1.Cout = (int)O1; g1.KS = 1; g1.stride = 1; g1.pad = 0; g1.up = 0; g1.M = M; g1.K = C; g1.geglu = 1;
+    g1.ln_stat = stat; g1.ln_parts = 1; g1.ln_C = C; g1.ln_eps = ln_eps; g1.ln_wsum = wsum;
+    g2.x = hid; g2.ldx = H4; g2.w = w2p; g2.bias = b2p; g2.res = p.x; g2.ldres = C; g2.y = p.y; g2.ldy = C; g2.N = 1; g2.H = M; g2.W = 1;
+    g2.Cin = (int)H4; g2.OH = M; g2.OW = 1; g2.Cout = C; g2.KS = 1; g2.stride = 1; g2.pad = 0; g2.up = 0; g2.M = M; g2.K = (int)H4;
+    float* partial = nullptr;
+    if (!use_fused || ms_per_launch) {
+        const long pf = igemm2_partial_floats(g2);
+        if (pf > 0) SD_DEV_ALLOC(scope, partial, (size_t)pf * 4);
+    }
+    auto two_gemms = [&]() { int r = launch_igemm2(g1, nullptr, s); return r ? r : launch_igemm2(g2, partial, s); };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ms_per_launch) { SD_HIP_CHECK(hipEventCreate(&e0)); SD_HIP_CHECK(hipEventCreate(&e1)); }
+    const int n = ms_per_launch ? iters + 2 : 1;
+    for (int it = 0; it < n && !rc; ++it) {
+        if (ms_per_launch && it == 2) SD_HIP_CHECK(hipEventRecord(e0, s));
+        rc = use_fused ? launch_ffn_fused(p, s) : two_gemms();
+    }
+    if (ms_per_launch && !rc) {
+        SD_HIP_CHECK(hipEventRecord(e1, s));
+        SD_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms_per_launch[0] = ms / (float)iters;
+        if (use_fused) {                 // [1]: the two-GEMM form on the same operands
+            for (int it = 0; it < 2 && !rc; ++it) rc = two_gemms();
+            SD_HIP_CHECK(hipEventRecord(e0, s));
+            for (int it = 0; it < iters && !rc; ++it) rc = two_gemms();
+            SD_HIP_CHECK(hipEventRecord(e1, s));
+            SD_HIP_CHECK(hipEventSynchronize(e1));
+            SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            ms_per_launch[1] = ms / (float)iters;
+            if (!rc) rc = launch_ffn_fused(p, s);          // leave the fused result in y
+        } else {
+            ms_per_launch[1] = ms_per_launch[0];
+        }
+    }
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
 int sd_bench_conv2d(const void* x, const void* w_oihw, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
                     int stride, int upsample2x, int geglu, int iters, float* ms_per_launch, void* stream) {
     if (iters < 1 || !ms_per_launch) { set_error("sd_bench_conv2d: bad arguments"); return SD_ERR_INVALID; }

@@ -166,6 +166,9 @@ void op_gn_conv(Ctx& c, const NormW& n, const ConvW& w, View x, int N, int H, in
                 const GnStatBuf* pre, const float* rowadd = nullptr, int rowadd_ld = 0, const View* res = nullptr,
                 const ConvFuse* fuse = nullptr);
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps);
+// y = x + GEGLU(LN(x) ff1) ff2 in one launch (ffn.hip) when the problem fits it (C = 320, LayerNorm folded into ff1, the
+// row statistics of x at hand); returns false -- nothing launched -- when it does not: the caller runs the two GEMMs.
+bool op_ffn_fused(Ctx& c, const ConvW& ff1, const ConvW& ff2, View x, const RowStat& x_stat, float ln_eps, long M, View y);
 void op_attention(Ctx& c, View q, View k, View v, View out, int B, int Tq, int Tk, int heads, int d, int causal = 0,
                   int prescaled = 0);
 

@@ -96,6 +96,20 @@ int launch_wsgemm(const IGemmParams& p, hipStream_t s);
 bool pgemm_geglu_supported(const IGemmParams& p);
 int launch_pgemm_geglu(const IGemmParams& p, hipStream_t s);
 
+// Fused GEGLU feed-forward (ffn.hip): out = x + GEGLU(LN(x) W1^T + b1) W2^T + b2 with the 4C-wide hidden tensor kept in
+// LDS / registers (C = 320: the 64 x 64 level of the SD1.5 UNet).  W1 / b1 / wsum1 are the LayerNorm-folded, GEGLU-packed
+// projection (WeightStore::pack_geglu + fold_ln), W2 / b2 the packed output linear; ln_stat the row statistics of x.
+struct FfnParams {
+    const half_t* x; long ldx;          // [M, C]: input of the block and its residual
+    half_t* y; long ldy;                // [M, C]
+    const half_t* w1; const float* b1; const float* wsum1; int w1_rows;     // [w1_rows >= 8C][C]
+    const half_t* w2; const float* b2; int w2_rows;                          // [w2_rows >= 384][4C]
+    const float* ln_stat; int ln_parts; float ln_eps;
+    int M, C, hidden;
+};
+bool ffn_fused_supported(const FfnParams& p);
+int launch_ffn_fused(const FfnParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // Normalisation (norm.hip)
 // ---------------------------------------------------------------------------------------------

@@ -506,6 +506,27 @@ void op_gn_conv(Ctx& c, const NormW& n, const ConvW& w, View x, int N, int H, in
     c.arena->release(mk);
 }
 
+bool op_ffn_fused(Ctx& c, const ConvW& ff1, const ConvW& ff2, View x, const RowStat& x_stat, float ln_eps, long M, View y) {
+    FfnParams p;
+    p.x = x.p; p.ldx = x.ld; p.y = y.p; p.ldy = y.ld;
+    p.w1 = ff1.w; p.b1 = ff1.bias; p.wsum1 = ff1.wsum;
+    p.w1_rows = (int)(((long)ff1.cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad);
+    p.w2 = ff2.w; p.b2 = ff2.bias;
+    p.w2_rows = (int)(((long)ff2.cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad);
+    p.ln_stat = x_stat.p; p.ln_parts = x_stat.parts; p.ln_eps = ln_eps;
+    p.M = (int)M; p.C = (int)ff1.K; p.hidden = (int)ff2.K;
+    if (c.dry) p.ln_stat = reinterpret_cast<const float*>(8);          // planning pass: only "is set" matters
+    if (ff1.ks != 1 || ff2.ks != 1 || ff2.cout != ff1.K || ff1.cout != 2 * ff2.K || x.C != p.C || !ff1.wsum) return false;
+    if (c.dry ? !(p.C == 320 && p.hidden == 1280 && M % 128 == 0 && M / 128 >= 64 && !getenv("SD_NO_FFN_FUSE")) : !ffn_fused_supported(p))
+        return false;
+    if (c.dry || c.err) return true;
+    prof_open(c.stream, "ffn_fused_kernel", 2.0 * M * ((double)ff1.cout * ff1.K + (double)ff2.cout * ff2.K),
+              2.0 * ((double)M * p.C * 2 + (double)ff1.cout * ff1.K + (double)ff2.cout * ff2.K));
+    c.err = launch_ffn_fused(p, c.stream);
+    prof_close(c.stream);
+    return true;
+}
+
 void op_layernorm(Ctx& c, const NormW& n, View x, View y, long rows, float eps) {
     if (c.dry || c.err) return;
     prof_open(c.stream, "layernorm_kernel", 0.0, 4.0 * rows * n.C);

@@ -334,14 +334,19 @@ void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out
         op_attention(c, q, text_kv.slice(b.kv_off, C), text_kv.slice(b.kv_off + C, C), att, N, T, L, t.heads, d, 0, 1);
         View t3(a.alloc_h(M * C), C, C);
         op_conv(c, b.out2, att, N, H, W, t3, 1, 0, nullptr, 0, &t2, 0, -1, 0, fold ? &f_t3 : nullptr);
-        View g(a.alloc_h(M * 4 * C), 4 * C, 4 * C);
-        if (fold) {
-            op_conv(c, b.ff1, t3, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1, -1, 0, &f_ln3);
-        } else {
-            op_layernorm(c, b.ln3, t3, n, M, 1e-5f);
-            op_conv(c, b.ff1, n, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1);
+        // norm3 -> GEGLU feed-forward -> + residual: one launch with the 4C-wide hidden tensor kept on the CU where the
+        // problem fits it (the 64 x 64 level: ffn.hip), otherwise the projection with its GEGLU epilogue and the output
+        // linear with its residual epilogue
+        if (!(fold && !more && op_ffn_fused(c, b.ff1, b.ff2, t3, st_t3, 1e-5f, M, nxt))) {
+            View g(a.alloc_h(M * 4 * C), 4 * C, 4 * C);
+            if (fold) {
+                op_conv(c, b.ff1, t3, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1, -1, 0, &f_ln3);
+            } else {
+                op_layernorm(c, b.ln3, t3, n, M, 1e-5f);
+                op_conv(c, b.ff1, n, N, H, W, g, 1, 0, nullptr, 0, nullptr, 1);
+            }
+            op_conv(c, b.ff2, g, N, H, W, nxt, 1, 0, nullptr, 0, &t3, 0, -1, 0, (fold && more) ? &f_cur : nullptr);
         }
-        op_conv(c, b.ff2, g, N, H, W, nxt, 1, 0, nullptr, 0, &t3, 0, -1, 0, (fold && more) ? &f_cur : nullptr);
         a.release(mb);
         View tmp = cur; cur = nxt; nxt = tmp;
     }
