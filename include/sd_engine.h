@@ -270,6 +270,20 @@ int sd_op_groupnorm_conv2d(const void* x_nhwc, const void* gamma, const void* be
                            const void* w_oihw, const void* bias, const void* rowadd, const void* res_nhwc, void* y_nhwc,
                            int N, int H, int W, int Cin, int Cout, int ksize, int iters, float* ms_per_launch, int* fused,
                            void* stream);
+/* The two ends of the UNet as one launch each (edge.hip; diffusers UNet2DConditionModel.forward: conv_in, and
+ * conv_norm_out -> conv_act -> conv_out, under sd_unified_pipeline.py:475-482).
+ * sd_op_unet_conv_in: y_nhwc [N H W, 320] f16 = conv3x3(x_nchw [N, Cin, H, W] f16; w_oihw [320, Cin, 3, 3] f16) + bias (f32),
+ *   9 Cin <= 64 and H W % 128 == 0.  groups > 0: gn_summaries [N][H W / 128][groups][2] f32 (device) receives (mean, M2) of
+ *   every 128-pixel tile x group of the stored output -- what the first resnet's GroupNorm merges instead of reading y.
+ * sd_op_unet_conv_out: y_nchw [N, Cout <= 4, H, W] f16 = conv3x3(act(GroupNorm(x_nhwc [N H W, 320]; gamma, beta, groups, eps));
+ *   w_oihw [Cout, 320, 3, 3]) + bias, act = SiLU when silu != 0; H % 8 == 0, W % 16 == 0, groups <= 32.
+ * Both return SD_ERR_INVALID for shapes the one-launch kernels do not take (the UNet then runs its general path);
+ * iters > 0: timed like sd_bench_conv2d (packing and the statistics pass outside the timed launches). */
+int sd_op_unet_conv_in(const void* x_nchw, const void* w_oihw, const void* bias, void* y_nhwc, float* gn_summaries, int groups,
+                       int N, int Cin, int H, int W, int Cout, int iters, float* ms_per_launch, void* stream);
+int sd_op_unet_conv_out(const void* x_nhwc, const void* gamma, const void* beta, int groups, float eps, int silu,
+                        const void* w_oihw, const void* bias, void* y_nchw, int N, int H, int W, int C, int Cout, int iters,
+                        float* ms_per_launch, void* stream);
 /* The GEGLU feed-forward of BasicTransformerBlock with its norm and residual (diffusers attention.py: norm3 -> FeedForward
  * (GEGLU) -> + hidden_states, under sd_unified_pipeline.py:475-482):
  *   y = x + (h * gelu(g)) W2^T + b2,   [h | g] = LayerNorm(x; gamma, beta, eps) W1^T + b1

@@ -124,6 +124,8 @@ SIGNATURES = {
                                     C.POINTER(_I), _P]),
     "sd_op_groupnorm_conv2d": (_I, [_P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F),
                                     C.POINTER(_I), _P]),
+    "sd_op_unet_conv_in": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _P]),
+    "sd_op_unet_conv_out": (_I, [_P, _P, _P, _I, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _P]),
     "sd_op_ffn_geglu": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_I), _P]),
     "sd_bench_conv2d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _P]),
     "sd_op_groupnorm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),

@@ -584,6 +584,95 @@ int sd_op_ffn_geglu(const void* x, const void* ln_gamma, const void* ln_beta, fl
     return rc;
 }
 
+int sd_op_unet_conv_in(const void* x_nchw, const void* w_oihw, const void* bias_f32, void* y_nhwc, float* gn_summaries,
+                       int groups, int N, int Cin, int H, int W, int Cout, int iters, float* ms_per_launch, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!x_nchw || !w_oihw || !bias_f32 || !y_nhwc || N < 1 || Cin < 1) { set_error("sd_op_unet_conv_in: bad arguments"); return SD_ERR_INVALID; }
+    const long K = 64;
+    const long rows = ((long)Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    DevScope scope;
+    half_t* wp = nullptr;
+    float* bp = nullptr;
+    SD_DEV_ALLOC(scope, wp, (size_t)rows * K * 2);
+    SD_DEV_ALLOC(scope, bp, (size_t)rows * 4);
+    SD_HIP_CHECK(hipMemsetAsync(wp, 0, (size_t)rows * K * 2, s));
+    SD_HIP_CHECK(hipMemsetAsync(bp, 0, (size_t)rows * 4, s));
+    HeadParams p;
+    p.x_nchw = static_cast<const half_t*>(x_nchw); p.w = wp; p.K = K; p.bias = bp; p.y = static_cast<half_t*>(y_nhwc); p.ldy = Cout;
+    p.gnstat_out = groups > 0 ? gn_summaries : nullptr; p.G = groups;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    if (9 * Cin > K || !conv_head_supported(p)) { set_error("sd_op_unet_conv_in: shape outside the one-launch kernel (Cout 320, 9 Cin <= 64, H W % 128 == 0)"); return SD_ERR_INVALID; }
+    int rc = launch_pack_conv(static_cast<const half_t*>(w_oihw), wp, Cout, Cin, 3, 3, K, s);
+    if (!rc) SD_HIP_CHECK(hipMemcpyAsync(bp, bias_f32, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = iters > 0 && ms_per_launch;
+    if (timed) { SD_HIP_CHECK(hipEventCreate(&e0)); SD_HIP_CHECK(hipEventCreate(&e1)); }
+    const int n = timed ? iters + 2 : 1;
+    for (int it = 0; it < n && !rc; ++it) {
+        if (timed && it == 2) SD_HIP_CHECK(hipEventRecord(e0, s));
+        rc = launch_conv_head(p, s);
+    }
+    if (timed && !rc) {
+        SD_HIP_CHECK(hipEventRecord(e1, s));
+        SD_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_launch = ms / (float)iters;
+    }
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
+int sd_op_unet_conv_out(const void* x_nhwc, const void* gamma_f32, const void* beta_f32, int groups, float eps, int silu,
+                        const void* w_oihw, const void* bias_f32, void* y_nchw, int N, int H, int W, int C, int Cout, int iters,
+                        float* ms_per_launch, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!x_nhwc || !gamma_f32 || !beta_f32 || !w_oihw || !bias_f32 || !y_nchw || groups < 1 || C % 64 != 0) { set_error("sd_op_unet_conv_out: bad arguments"); return SD_ERR_INVALID; }
+    const long K = 9L * C;
+    const long rows = ((long)Cout + kWeightRowPad - 1) / kWeightRowPad * kWeightRowPad;
+    DevScope scope;
+    half_t* wp = nullptr;
+    float *bp = nullptr, *scratch = nullptr;
+    SD_DEV_ALLOC(scope, wp, (size_t)rows * K * 2);
+    SD_DEV_ALLOC(scope, bp, (size_t)rows * 4);
+    SD_DEV_ALLOC(scope, scratch, (size_t)gn_scratch_floats(N, (long)H * W, C, groups) * 4);
+    SD_HIP_CHECK(hipMemsetAsync(wp, 0, (size_t)rows * K * 2, s));
+    SD_HIP_CHECK(hipMemsetAsync(bp, 0, (size_t)rows * 4, s));
+    int rc = launch_pack_conv(static_cast<const half_t*>(w_oihw), wp, Cout, C, 3, 3, K, s);
+    if (!rc) SD_HIP_CHECK(hipMemcpyAsync(bp, bias_f32, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s));
+    GnStats st;
+    if (!rc) rc = launch_gn_stats(static_cast<const half_t*>(x_nhwc), C, N, (long)H * W, C, groups, scratch, &st, s);
+    if (rc) return rc;
+    TailParams p;
+    p.x = static_cast<const half_t*>(x_nhwc); p.ldx = C;
+    p.gn_part = st.part; p.gn_S = st.S; p.gn_rows = st.rows;
+    p.G = groups; p.eps = eps; p.gamma = static_cast<const float*>(gamma_f32); p.beta = static_cast<const float*>(beta_f32); p.silu = silu;
+    p.w = wp; p.K = K; p.bias = bp; p.y = static_cast<half_t*>(y_nchw);
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Cout = Cout;
+    if (!conv_tail_supported(p)) { set_error("sd_op_unet_conv_out: shape outside the one-launch kernel (C 320, Cout <= 4, H % 8 == 0, W % 16 == 0, groups <= 32)"); return SD_ERR_INVALID; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = iters > 0 && ms_per_launch;
+    if (timed) { SD_HIP_CHECK(hipEventCreate(&e0)); SD_HIP_CHECK(hipEventCreate(&e1)); }
+    const int n = timed ? iters + 2 : 1;
+    for (int it = 0; it < n && !rc; ++it) {
+        if (timed && it == 2) SD_HIP_CHECK(hipEventRecord(e0, s));
+        rc = launch_conv_tail(p, s);
+    }
+    if (timed && !rc) {
+        SD_HIP_CHECK(hipEventRecord(e1, s));
+        SD_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SD_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_launch = ms / (float)iters;
+    }
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
 int sd_bench_conv2d(const void* x, const void* w_oihw, void* y, int N, int H, int W, int Cin, int Cout, int ksize,
                     int stride, int upsample2x, int geglu, int iters, float* ms_per_launch, void* stream) {
     if (iters < 1 || !ms_per_launch) { set_error("sd_bench_conv2d: bad arguments"); return SD_ERR_INVALID; }

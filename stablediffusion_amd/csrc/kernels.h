@@ -182,6 +182,34 @@ int launch_pointwise_nchw(const half_t* x, const half_t* w, const float* bias, h
 constexpr long kSmallCoutMinPixels = 131072;
 int launch_conv3x3_small_cout(const half_t* x, long ldx, const half_t* w, long K, const float* bias, half_t* y_nchw,
                               int N, int H, int W, int Cin, int Cout, hipStream_t s);
+// ---- the two ends of the UNet (edge.hip) ----
+// conv_in: x NCHW f16 [N, Cin, H, W] (9 Cin <= 64) -> y NHWC [N H W, 320] (row stride ldy) = conv3x3(x) + bias, packed
+// weights [>= 320][64] (k = (kh, kw, ci), zero from 9 Cin up: WeightStore::pack_conv's layout).  gnstat_out != nullptr:
+// also the GroupNorm summaries of y for G groups in the IGemmParams::gnstat_out layout with 128-row tiles
+// (GnStats{part = gnstat_out, S = H W / 128, rows = 128}).
+struct HeadParams {
+    const half_t* x_nchw = nullptr;
+    const half_t* w = nullptr; long K = 0;
+    const float* bias = nullptr;
+    half_t* y = nullptr; long ldy = 0;
+    float* gnstat_out = nullptr; int G = 0;
+    int N = 0, Cin = 0, H = 0, W = 0, Cout = 0;
+};
+bool conv_head_supported(const HeadParams& p);
+int launch_conv_head(const HeadParams& p, hipStream_t s);
+// norm_out -> SiLU -> conv_out: y NCHW f16 [N, Cout <= 4, H, W] = conv3x3(act(GroupNorm(x))) + bias; x NHWC (row stride
+// ldx), GroupNorm summaries of x as (gn_part, gn_S, gn_rows) (GnStats), packed weights [>= Cout][K = 9 C] in
+// pack_conv's K order [C / 64][kh][kw][64].
+struct TailParams {
+    const half_t* x = nullptr; long ldx = 0;
+    const float* gn_part = nullptr; int gn_S = 0; long gn_rows = 0;
+    int G = 0; float eps = 0.f; const float* gamma = nullptr; const float* beta = nullptr; int silu = 0;
+    const half_t* w = nullptr; long K = 0; const float* bias = nullptr;
+    half_t* y = nullptr;
+    int N = 0, H = 0, W = 0, C = 0, Cout = 0;
+};
+bool conv_tail_supported(const TailParams& p);
+int launch_conv_tail(const TailParams& p, hipStream_t s);
 // Weight packing: OIHW -> [O][KH][KW][I(+pad)] rows; Kpad >= KH*KW*I.
 int launch_pack_conv(const half_t* w_oihw, half_t* wp, int O, int I, int KH, int KW, long Kpad,
                      hipStream_t s);

@@ -453,19 +453,39 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     ctx_gnpool_init(c, B, (long)H * W, G);
     GnStatBuf* xs = nullptr;
 
-    // ---- conv_in (Cin = 4: im2col into a 64-wide K, then the GEMM kernel) ----
+    // ---- conv_in: one launch straight from the NCHW latents (edge.hip); otherwise (inpainting's 9 channels, odd maps)
+    //      im2col into a 64-wide K, then the GEMM kernel ----
     int h = H, w = W;
     {
         const size_t mk = a.mark();
         const long M = (long)B * H * W;
-        half_t* col = a.alloc_h(M * conv_in.K);
-        if (go && !c.err) c.err = launch_im2col_nchw3x3(sample, col, B, cfg.in_channels, H, W, (int)conv_in.K, s);
-        ConvW pw = conv_in; pw.ks = 1;
-        ConvFuse f;
-        f.gn_out = gn_wants_stats((long)H * W, boc[0], G) ? ctx_gnbuf(c) : nullptr;
-        f.gn_groups = G;
-        op_conv(c, pw, View(col, conv_in.K, (int)conv_in.K), B, H, W, skip_view(skip_i), 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
-        xs = f.gn_out;
+        GnStatBuf* gb = gn_wants_stats((long)H * W, boc[0], G) ? ctx_gnbuf(c) : nullptr;
+        const View y0 = skip_view(skip_i);
+        HeadParams hp;
+        hp.x_nchw = sample; hp.w = conv_in.w; hp.K = conv_in.K; hp.bias = conv_in.bias; hp.y = y0.p; hp.ldy = y0.ld;
+        hp.gnstat_out = (gb && gb->buf) ? gb->buf : nullptr; hp.G = G;
+        hp.N = B; hp.Cin = cfg.in_channels; hp.H = H; hp.W = W; hp.Cout = boc[0];
+        if (conv_head_supported(hp)) {
+            if (gb) {
+                gb->st = GnStats();
+                if (hp.gnstat_out) { gb->st.part = gb->buf; gb->st.rows = 128; gb->st.S = (int)((long)H * W / 128); }
+            }
+            if (go && !c.err) {
+                prof_open(s, "conv_head_kernel", 2.0 * M * boc[0] * 9.0 * cfg.in_channels, 2.0 * M * (boc[0] + cfg.in_channels));
+                c.err = launch_conv_head(hp, s);
+                prof_close(s);
+            }
+            xs = gb;
+        } else {
+            half_t* col = a.alloc_h(M * conv_in.K);
+            if (go && !c.err) c.err = launch_im2col_nchw3x3(sample, col, B, cfg.in_channels, H, W, (int)conv_in.K, s);
+            ConvW pw = conv_in; pw.ks = 1;
+            ConvFuse f;
+            f.gn_out = gb;
+            f.gn_groups = G;
+            op_conv(c, pw, View(col, conv_in.K, (int)conv_in.K), B, H, W, y0, 1, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
+            xs = f.gn_out;
+        }
         a.release(mk);
     }
     View x = skip_view(skip_i++);
@@ -563,6 +583,20 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     {
         const int C = boc[0];
         const long M = (long)B * h * w;
+        TailParams tp;
+        tp.x = final_x.p; tp.ldx = final_x.ld;
+        if (xs && xs->st.part) { tp.gn_part = xs->st.part; tp.gn_S = xs->st.S; tp.gn_rows = xs->st.rows; }
+        tp.G = G; tp.eps = eps; tp.gamma = norm_out.gamma; tp.beta = norm_out.beta; tp.silu = 1;
+        tp.w = conv_out.w; tp.K = conv_out.K; tp.bias = conv_out.bias; tp.y = out;
+        tp.N = B; tp.H = h; tp.W = w; tp.C = C; tp.Cout = cfg.out_channels;
+        // (dry run: xs->st is only filled by real launches; the fused tail allocates nothing, so both plans fit)
+        if (go && !c.err && conv_tail_supported(tp)) {
+            // GroupNorm + SiLU + convolution + NCHW in one launch (edge.hip)
+            prof_open(s, "conv_tail_kernel", 2.0 * M * cfg.out_channels * 9.0 * C, 2.0 * M * (C + cfg.out_channels));
+            c.err = launch_conv_tail(tp, s);
+            prof_close(s);
+            return c.err;
+        }
         View hn(a.alloc_h(M * C), C, C);
         op_groupnorm(c, norm_out, final_x, hn, B, (long)h * w, G, eps, 1, xs);
         if (cfg.out_channels <= 4 && conv_out.ks == 3 && conv_out.K == 9L * C && M >= kSmallCoutMinPixels) {

@@ -592,3 +592,72 @@ def test_ffn_geglu_fused(engine_lib, M, C, scale):
     engine_lib.sd_op_ffn_geglu(P(xd), P(gd), P(bd), 1e-5, P(w1d), P(b1d), P(w2d), P(b2d), P(y2), M, C, 0, None, None, stream())
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("N,Cin,H,W", [(8, 4, 64, 64), (2, 4, 16, 16), (1, 4, 128, 128), (2, 7, 16, 24)])
+def test_unet_conv_in_one_launch(engine_lib, N, Cin, H, W):
+    """conv_head_kernel: conv_in straight from the NCHW latents (im2col tile in LDS), output NHWC, plus the GroupNorm
+    summaries (mean, M2) of every 128-pixel tile x group of the STORED fp16 output."""
+    import ctypes
+    Cout, G = 320, 32
+    g = torch.Generator().manual_seed(N * H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).half()
+    b = torch.randn(Cout, generator=g) * 0.3
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    y = torch.zeros(N, H, W, Cout, dtype=torch.float16, device="cuda")
+    S = H * W // 128
+    summ = torch.zeros(N, S, G, 2, dtype=torch.float32, device="cuda")
+    xd, wd, bd = h(x), h(w), b.cuda()
+    rc = engine_lib.sd_op_unet_conv_in(P(xd), P(wd), P(bd), P(y), P(summ), G, N, Cin, H, W, Cout, 0, None, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    out = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(out, ref) < 1e-3, rel_l2(out, ref)
+    ring = torch.ones(H, W, dtype=torch.bool)
+    ring[1:-1, 1:-1] = False
+    assert rel_l2(out[:, :, ring], ref[:, :, ring]) < 1e-3
+    # summaries of the stored values, tile = 128 consecutive pixels of one image
+    t = y.float().cpu().reshape(N, S, 128, G, Cout // G)
+    mean = t.mean(dim=(2, 4))
+    m2 = ((t - mean[:, :, None, :, None]) ** 2).sum(dim=(2, 4))
+    got = summ.cpu()
+    assert torch.allclose(got[..., 0], mean, atol=2e-5, rtol=1e-4)
+    assert torch.allclose(got[..., 1], m2, atol=1e-3, rtol=1e-4)
+
+
+def test_unet_conv_in_refuses_other_shapes(engine_lib):
+    x = torch.zeros(1, 9, 16, 16, dtype=torch.float16, device="cuda")          # inpainting's 9 channels: K = 81 > 64
+    w = torch.zeros(320, 9, 3, 3, dtype=torch.float16, device="cuda")
+    b = torch.zeros(320, device="cuda")
+    y = torch.zeros(1, 16, 16, 320, dtype=torch.float16, device="cuda")
+    assert engine_lib.sd_op_unet_conv_in(P(x), P(w), P(b), P(y), None, 0, 1, 9, 16, 16, 320, 0, None, stream()) != 0
+    assert b"one-launch" in engine_lib.sd_last_error()
+
+
+@pytest.mark.parametrize("N,H,W,Cout,silu", [(8, 64, 64, 4, 1), (2, 16, 16, 4, 1), (1, 128, 128, 4, 1), (2, 8, 32, 3, 0)])
+def test_unet_conv_out_one_launch(engine_lib, N, H, W, Cout, silu):
+    """conv_tail_kernel: GroupNorm + SiLU + 3x3 convolution to <= 4 channels + NCHW in one launch against
+    group_norm -> silu -> conv2d in fp32 (the normalised activations are rounded to fp16 once, as the separate kernels do)."""
+    C_, G = 320, 32
+    g = torch.Generator().manual_seed(N * H + Cout)
+    x = (torch.randn(N, C_, H, W, generator=g) * (1 + torch.rand(1, C_, 1, 1, generator=g)) + torch.randn(1, C_, 1, 1, generator=g)).half()
+    gamma = 1 + 0.2 * torch.randn(C_, generator=g)
+    beta = 0.2 * torch.randn(C_, generator=g)
+    w = (torch.randn(Cout, C_, 3, 3, generator=g) / (9 * C_) ** 0.5).half()
+    b = torch.randn(Cout, generator=g) * 0.3
+    hn = F.group_norm(x.float(), G, gamma, beta, 1e-5)
+    if silu:
+        hn = F.silu(hn)
+    ref = F.conv2d(hn, w.float(), b, padding=1)
+    y = torch.zeros(N, Cout, H, W, dtype=torch.float16, device="cuda")
+    xd, wd = h(x.permute(0, 2, 3, 1)), h(w)
+    gd, btd, bd = gamma.cuda(), beta.cuda(), b.cuda()
+    rc = engine_lib.sd_op_unet_conv_out(P(xd), P(gd), P(btd), G, 1e-5, silu, P(wd), P(bd), P(y), N, H, W, C_, Cout, 0, None, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    out = y.float().cpu()
+    assert rel_l2(out, ref) < 3e-3, rel_l2(out, ref)
+    ring = torch.ones(H, W, dtype=torch.bool)
+    ring[1:-1, 1:-1] = False
+    assert rel_l2(out[:, :, ring], ref[:, :, ring]) < 4e-3
