@@ -705,11 +705,20 @@ int sd_bench_groupnorm(const void* x, const void* gamma_f32, const void* beta_f3
     SD_HIP_CHECK(hipEventCreate(&e0));
     SD_HIP_CHECK(hipEventCreate(&e1));
     int rc = 0;
+    // SD_GN_BENCH_APPLY=1: the statistics pass runs once, outside the timed launches, and every timed launch is the
+    // apply pass alone on those summaries -- what a GroupNorm costs when the producing convolution left them
+    static const bool apply_only = getenv("SD_GN_BENCH_APPLY") != nullptr;
+    GnStats st;
+    float* scratch2 = nullptr;
+    if (apply_only && gn_wants_stats(HW, C, groups)) {
+        SD_DEV_ALLOC(scope, scratch2, (size_t)gn_scratch_floats(N, HW, C, groups) * 4);
+        rc = launch_gn_stats(static_cast<const half_t*>(x), C, N, HW, C, groups, scratch2, &st, s);
+    }
     for (int i = 0; i < iters + 2 && !rc; ++i) {
         if (i == 2) (void)hipEventRecord(e0, s);
         rc = launch_groupnorm(static_cast<const half_t*>(x), C, static_cast<const float*>(gamma_f32),
                               static_cast<const float*>(beta_f32), static_cast<half_t*>(y), C, N, HW, C, groups,
-                              eps, silu, scratch, s);
+                              eps, silu, scratch, s, st.part ? &st : nullptr);
     }
     (void)hipEventRecord(e1, s);
     hipError_t e = hipEventSynchronize(e1);

@@ -274,24 +274,82 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(const half_t* __restrict
     const bool active = prow < rows_par;
     const long row0 = (long)blockIdx.x * rows_par * NV;
     const half_t* xb = x + ((long)n * HW) * ldx + c0 + chunk * 8;
-    h8 v[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const long pr = row0 + prow + (long)k * rows_par;
-        if (active && pr < HW) v[k] = *reinterpret_cast<const h8*>(xb + pr * ldx);
-    }
     const int cpg = C / G;
     const int ng = cw / cpg, g0 = c0 / cpg;
-    const int parts = 256 / ng;
-    // (the affine of this thread's eight channels: loaded here so that its round trip overlaps the summaries')
+    // The prologue runs in EVERY block (1368 of them on 32768 x 320) and all blocks of an image read the SAME 4 KB of
+    // summaries at the same time: with all four waves loading them (pivot + 2 per thread) the requests pile up on a few
+    // L2 lines, and with S = 0 (nothing to load) the kernel ran 10.5 instead of 14.7 us (SD_GN_DBG_S0 experiment,
+    // profiles/r03_groupnorm_apply.txt).  They are fetched by as few waves as the count allows (below) and merged without
+    // divisions:
+    // equal-count summaries (every slab has stat_rows rows), p = the first slab's mean,
+    //   a = sum (m_k - p),  b = sum (m_k - p)^2,  q = sum M2_k:   mean = p + a / S,   M2 = q + cnt (b - a^2 / S)
+    // (the shift by p keeps b - a^2 / S free of cancellation whatever |mean| / std is).  A ragged last slab takes the
+    // general chan_merge path.
+    const bool equal = HW % stat_rows == 0;
+    constexpr int KPRE = 4;
+    // few summaries (S * ng <= 128: the 32 x 32 maps): wave 0 alone fetches and merges them -- no second barrier, the
+    // other waves go straight to the one below (10.3 -> 7.7 us on 8192 x 640); many (64 x 64 maps, S = 16): all four
+    // waves share the fetch, two per thread (one wave with eight per lane: 17.2 us against 12.9)
+    const int LW = (equal && S * ng <= 128 && ng <= 64) ? 1 : 4;
+    const int parts1 = 64 * LW / ng;                         // threads per group (ng <= 128: launcher)
+    const int gi = tid % ng, pi = tid / ng;
+    const bool fetch = tid < 64 * LW;                        // wave-uniform
+    const bool loader = fetch && pi < parts1;
+    const float* src = part + ((long)n * S * G + g0 + gi) * 2;
+    // (every load below is unconditional on a clamped index: a load under a lane condition becomes a branch, and the
+    //  compiler put s_waitcnt vmcnt(0) between such branches -- the loads went out one round trip at a time)
+    float2 pre[KPRE];
+    float pivot = 0.f;
+    if (fetch) {
+        pivot = src[0];
+#pragma unroll
+        for (int j = 0; j < KPRE; ++j) {
+            int k = pi + j * parts1;
+            k = k < S ? k : (S > 0 ? S - 1 : 0);
+            pre[j] = *reinterpret_cast<const float2*>(src + (long)k * G * 2);
+        }
+    }
     const int cch = active ? c0 + chunk * 8 : 0;
     const f4 ga = *reinterpret_cast<const f4*>(gamma + cch), gb = *reinterpret_cast<const f4*>(gamma + cch + 4);
     const f4 ba = *reinterpret_cast<const f4*>(beta + cch), bb = *reinterpret_cast<const f4*>(beta + cch + 4);
-    {
-        const int gi = tid % ng, pi = tid / ng;
+    h8 v[NV];
+    const half_t* xt = active ? xb : x + ((long)n * HW) * ldx;        // idle threads (256 % chunks-per-row of them) read a valid address
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        long pr = row0 + prow + (long)k * rows_par;
+        pr = pr < HW ? pr : HW - 1;
+        v[k] = *reinterpret_cast<const h8*>(xt + (active ? pr : 0) * ldx);
+    }
+    if (equal) {
+        float sa = 0.f, sb = 0.f, sq = 0.f;
+        if (fetch) {
+            if (loader) {
+#pragma unroll
+                for (int j = 0; j < KPRE; ++j)
+                    if (pi + j * parts1 < S) { const float d = pre[j].x - pivot; sa += d; sb += d * d; sq += pre[j].y; }
+                for (int k = pi + KPRE * parts1; k < S; k += parts1) {      // (more than KPRE per thread: the VAE's big maps)
+                    const float d = src[(long)k * G * 2] - pivot;
+                    sa += d; sb += d * d; sq += src[(long)k * G * 2 + 1];
+                }
+            }
+            red[tid * 3] = sa; red[tid * 3 + 1] = sb; red[tid * 3 + 2] = sq;
+        }
+        if (LW == 4) __syncthreads();                        // (LW == 1: writer and reader are the same wave, LDS is in order)
+        if (tid < ng) {
+            sa = 0.f; sb = 0.f; sq = 0.f;
+            for (int k = 0; k < parts1; ++k) { sa += red[(k * ng + tid) * 3]; sb += red[(k * ng + tid) * 3 + 1]; sq += red[(k * ng + tid) * 3 + 2]; }
+            const float invS = __builtin_amdgcn_rcpf((float)S);
+            const float dm = sa * invS;
+            const float cnt = (float)stat_rows * (float)cpg;
+            const float m2 = sq + cnt * (sb - sa * dm);
+            const float var = m2 * __builtin_amdgcn_rcpf((float)HW * (float)cpg);
+            st[tid * 2] = pivot + dm;
+            st[tid * 2 + 1] = rsqrtf((var < 0.f ? 0.f : var) + eps);
+        }
+    } else {
+        const int parts = 256 / ng;
         if (pi < parts) {
             float nA = 0.f, mA = 0.f, qA = 0.f;
-            const float* src = part + ((long)n * S * G + g0 + gi) * 2;
             for (int k = pi; k < S; k += parts) {
                 long rows = HW - (long)k * stat_rows;
                 if (rows > stat_rows) rows = stat_rows;
@@ -299,19 +357,32 @@ __global__ __launch_bounds__(256) void gn_apply2_kernel(const half_t* __restrict
             }
             red[(pi * ng + gi) * 3] = nA; red[(pi * ng + gi) * 3 + 1] = mA; red[(pi * ng + gi) * 3 + 2] = qA;
         }
-    }
-    __syncthreads();
-    if (tid < ng) {
-        float nA = red[tid * 3], mA = red[tid * 3 + 1], qA = red[tid * 3 + 2];
-        for (int k = 1; k < parts; ++k) chan_merge(nA, mA, qA, red[(k * ng + tid) * 3], red[(k * ng + tid) * 3 + 1], red[(k * ng + tid) * 3 + 2]);
-        const float var = qA / ((float)HW * (float)cpg);
-        st[tid * 2] = mA;
-        st[tid * 2 + 1] = rsqrtf((var < 0.f ? 0.f : var) + eps);
+        __syncthreads();
+        if (tid < ng) {
+            float nA = red[tid * 3], mA = red[tid * 3 + 1], qA = red[tid * 3 + 2];
+            for (int k = 1; k < parts; ++k) chan_merge(nA, mA, qA, red[(k * ng + tid) * 3], red[(k * ng + tid) * 3 + 1], red[(k * ng + tid) * 3 + 2]);
+            const float var = qA / ((float)HW * (float)cpg);
+            st[tid * 2] = mA;
+            st[tid * 2 + 1] = rsqrtf((var < 0.f ? 0.f : var) + eps);
+        }
     }
     __syncthreads();
     if (!active) return;
     float sc[8], sh[8];
-    {
+    if (cpg >= 8 || cpg == 4) {
+        // the thread's eight channels lie in at most two groups
+        const int cl = chunk * 8;
+        const int gA = (int)(((float)cl + 0.5f) * __builtin_amdgcn_rcpf((float)cpg));
+        const int split = (gA + 1) * cpg - cl;                 // channels e < split are in group gA
+        const int gB = split < 8 ? gA + 1 : gA;
+        const float mA_ = st[gA * 2], rA = st[gA * 2 + 1], mB_ = st[gB * 2], rB = st[gB * 2 + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float w = (e < split ? rA : rB) * (e < 4 ? ga[e] : gb[e - 4]);
+            sc[e] = w;
+            sh[e] = (e < 4 ? ba[e] : bb[e - 4]) - (e < split ? mA_ : mB_) * w;
+        }
+    } else {
         const float inv_cpg = 1.0f / (float)cpg;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -696,11 +767,11 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
     const int CB = gn_block_channels(C, G);
     if (!old && CB / (C / G) <= 128) {
         // channel-blocked apply: rows per block = (256 / chunks per row) x NV, NV the largest of 8 / 4 / 2 / 1 that still
-        // leaves about 1024 blocks (or one pixel row group per block on the small maps)
+        // leaves about 512 blocks (every block pays the summary prologue: fewer, longer blocks won the sweep) (or one pixel row group per block on the small maps)
         const int cblocks = cdiv(C, CB);
         const int rows_par = 256 / (CB / 8) > 0 ? 256 / (CB / 8) : 1;
         int nv = 8;
-        while (nv > 1 && cdiv(HW, (long)rows_par * nv) * cblocks * N < 1024) nv >>= 1;
+        while (nv > 1 && cdiv(HW, (long)rows_par * nv) * cblocks * N < 512) nv >>= 1;
         const dim3 grid((unsigned)cdiv(HW, (long)rows_par * nv), cblocks, N);
 #define SD_GN_APPLY2(NVV) hipLaunchKernelGGL((gn_apply2_kernel<NVV>), grid, dim3(256), 0, s, x, ldx, part, gamma, beta, y, ldy, HW, C, G, S, stat_rows, CB, eps, silu)
         if (nv == 8) SD_GN_APPLY2(8); else if (nv == 4) SD_GN_APPLY2(4); else if (nv == 2) SD_GN_APPLY2(2); else SD_GN_APPLY2(1);
