@@ -377,8 +377,10 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     float* tproj = a.alloc_f((long)B * temb_total);
     if (go && !c.err) c.err = launch_timestep_sinusoid(timesteps, 1, sinus, B, boc[0], cfg.flip_sin_to_cos, cfg.freq_shift, boc[0], s);
     if (go && !c.err) c.err = launch_small_linear(sinus, boc[0], te1.w, te1.bias, e1, temb, B, boc[0], temb, 0, 1, s);
-    if (go && !c.err) c.err = launch_small_linear(e1, temb, te2.w, te2.bias, emb, temb, B, temb, temb, 0, 0, s);
-    if (cfg.addition_time_embed_dim > 0) {
+    // (without text_time conditioning the SiLU every resnet applies to the embedding rides on this launch)
+    const bool aug_path = cfg.addition_time_embed_dim > 0;
+    if (go && !c.err) c.err = launch_small_linear(e1, temb, te2.w, te2.bias, emb, temb, B, temb, temb, 0, aug_path ? 0 : 1, s);
+    if (aug_path) {
         const int ad = cfg.addition_time_embed_dim;
         const int pin = cfg.projection_class_embeddings_input_dim;
         const int tdim = pin - 6 * ad;          // pooled text embedding width
@@ -402,8 +404,6 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
         if (go && !c.err) c.err = launch_small_linear(addin, pin, ae1.w, ae1.bias, a1, temb, B, pin, temb, 0, 1, s);
         if (go && !c.err) c.err = launch_small_linear(a1, temb, ae2.w, ae2.bias, aug, temb, B, temb, temb, 0, 0, s);
         if (go && !c.err) c.err = launch_add_f32(emb, aug, (long)B * temb, 1, s);      // silu(emb + aug_emb)
-    } else {
-        if (go && !c.err) c.err = launch_add_f32(emb, nullptr, (long)B * temb, 1, s);  // silu(emb)
     }
     // every resnet consumes the embedding only as time_emb_proj(silu(emb)): the SiLU is applied once
     // here instead of inside the weight-bandwidth-bound stacked GEMV

@@ -482,10 +482,12 @@ def test_timestep_sinusoid(engine_lib, dim, flip, shift):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,K,n_out,silu_in,silu_out", [(8, 320, 1280, 0, 1), (8, 1280, 1280, 0, 0), (2, 2816, 1280, 0, 1),
-                                                      (8, 1280, 320 * 22, 1, 0), (1, 64, 40, 1, 1)])
+                                                      (8, 1280, 320 * 22, 1, 0), (1, 64, 40, 1, 1),
+                                                      (16, 1280, 20160, 1, 0), (3, 320, 1280, 0, 1), (8, 96, 48, 0, 0)])
 def test_small_linear(engine_lib, B, K, n_out, silu_in, silu_out):
     """The time-embedding MLP linears (TimestepEmbedding.linear_1 / linear_2, SDXL add_embedding, the stacked
-    time_emb_proj of every resnet): fp32 activations, fp16 weights, optional SiLU before / after."""
+    time_emb_proj of every resnet): fp32 activations, fp16 weights, optional SiLU before / after.  K <= 1280 with
+    n_out % 16 == 0 runs skinny_linear_kernel (MFMA, x split hi + lo so that it stays fp32-exact), the rest the GEMV kernel."""
     g = torch.Generator().manual_seed(K + n_out)
     x = torch.randn(B, K, generator=g)
     w = (torch.randn(n_out, K, generator=g) / K ** 0.5).half()
