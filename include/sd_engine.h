@@ -302,6 +302,13 @@ int sd_bench_conv2d(const void* x_nhwc, const void* w_oihw, void* y_nhwc, int N,
 /* GroupNorm (+ optional SiLU) on NHWC f16, fp32 statistics. */
 int sd_op_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
                     int N, int HW, int C, int groups, float eps, int silu, void* stream);
+/* GroupNorm of a channel concatenation [A | B] (diffusers' up blocks: torch.cat([hidden_states, res_hidden_states], 1) ->
+ * ResnetBlock2D.norm1, under sd_unified_pipeline.py:475-482) from per-half summaries, the way the UNet runs it on its big
+ * maps: statistics of the first Ca channels over sub-groups of width gcd(C / groups, Ca), of the last Cb over their own
+ * `groups` groups, one small launch merging them per group of the concatenation, then the apply pass.  x, y [N HW, Ca + Cb]
+ * f16.  SD_ERR_INVALID when the halves' sub-groups cannot tile the groups (the UNet then runs an ordinary statistics pass). */
+int sd_op_groupnorm_concat(const void* x_nhwc, int Ca, int Cb, const void* gamma, const void* beta, void* y_nhwc, int N, int HW,
+                           int groups, float eps, int silu, void* stream);
 /* Same operator, timed like sd_bench_conv2d (scratch allocated once, `iters` launches between HIP events). */
 int sd_bench_groupnorm(const void* x_nhwc, const void* gamma, const void* beta, void* y_nhwc,
                        int N, int HW, int C, int groups, float eps, int silu, int iters,

@@ -129,6 +129,7 @@ SIGNATURES = {
     "sd_op_ffn_geglu": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), C.POINTER(_I), _P]),
     "sd_bench_conv2d": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), _P]),
     "sd_op_groupnorm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "sd_op_groupnorm_concat": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sd_bench_groupnorm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, C.POINTER(_F), _P]),
     "sd_op_timestep_sinusoid": (_I, [_P, _P, _I, _I, _I, _F, _P]),
     "sd_op_small_linear": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -694,6 +694,37 @@ int sd_op_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, 
     return rc;
 }
 
+int sd_op_groupnorm_concat(const void* x, int Ca, int Cb, const void* gamma_f32, const void* beta_f32, void* y, int N, int HW,
+                           int groups, float eps, int silu, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = Ca + Cb;
+    if (!x || !gamma_f32 || !beta_f32 || !y || Ca < 8 || Cb < 8 || groups < 1 || C % groups != 0 || Cb % groups != 0) {
+        set_error("sd_op_groupnorm_concat: bad arguments"); return SD_ERR_INVALID;
+    }
+    const int u = gn_cat_unit(Ca, Cb, groups), ub = Cb / groups;
+    if (!(u >= 8 || u == 4) || (C / groups) % ub != 0 || Ca % ub != 0 || !(ub >= 8 || ub == 4)) {
+        set_error("sd_op_groupnorm_concat: the halves' sub-groups do not tile the groups"); return SD_ERR_INVALID;
+    }
+    const int Ga = Ca / u;
+    DevScope scope;
+    float *sa = nullptr, *sb = nullptr, *fin = nullptr, *scratch = nullptr;
+    SD_DEV_ALLOC(scope, sa, (size_t)gn_scratch_floats(N, HW, Ca, Ga) * 4);
+    SD_DEV_ALLOC(scope, sb, (size_t)gn_scratch_floats(N, HW, Cb, groups) * 4);
+    SD_DEV_ALLOC(scope, fin, (size_t)N * groups * 2 * 4);
+    SD_DEV_ALLOC(scope, scratch, (size_t)gn_scratch_floats(N, HW, C, groups) * 4);
+    const half_t* xh = static_cast<const half_t*>(x);
+    GnStats sta, stb, stc;
+    int rc = launch_gn_stats(xh, C, N, HW, Ca, Ga, sa, &sta, s);                // the hidden half: Ga sub-groups of width u
+    if (!rc) rc = launch_gn_stats(xh + Ca, C, N, HW, Cb, groups, sb, &stb, s);   // the skip half: its own `groups` groups
+    if (!rc) rc = launch_gn_cat_finalize(sta, Ga, Ca, stb, groups, Cb, fin, N, HW, groups, s);
+    stc.part = fin; stc.S = 1; stc.rows = HW;
+    if (!rc) rc = launch_groupnorm(xh, C, static_cast<const float*>(gamma_f32), static_cast<const float*>(beta_f32),
+                                   static_cast<half_t*>(y), C, N, HW, C, groups, eps, silu, scratch, s, &stc);
+    hipError_t e = hipStreamSynchronize(s);
+    if (!rc && e != hipSuccess) { set_error(hipGetErrorString(e)); rc = SD_ERR_HIP; }
+    return rc;
+}
+
 int sd_bench_groupnorm(const void* x, const void* gamma_f32, const void* beta_f32, void* y, int N, int HW, int C,
                        int groups, float eps, int silu, int iters, float* ms_per_launch, void* stream) {
     if (iters < 1 || !ms_per_launch) { set_error("sd_bench_groupnorm: bad arguments"); return SD_ERR_INVALID; }

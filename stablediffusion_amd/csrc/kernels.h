@@ -132,6 +132,13 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
 int launch_gn_stats(const half_t* x, long ldx, int N, long HW, int C, int G, float* scratch, GnStats* st, hipStream_t s);
 // Merges the st.S summaries per image into one (into `out`, N * G * 2 floats) and rewrites *st to describe that.
 int launch_gn_finalize(GnStats* st, float* out, int N, long HW, int C, int G, hipStream_t s);
+// GroupNorm over a channel concatenation [A | B] from its two producers' summaries (norm.hip: gn_cat_finalize_kernel):
+// sa / sb describe summaries over Ga / Gb sub-groups of the Ca / Cb channels; out (N * G * 2 floats) receives one
+// (mean, M2) per image and group of the concatenation = GnStats{out, 1, HW}.  gn_cat_unit: the sub-group width A's
+// producer has to use; B's own width must divide both the channels per group and Ca.
+int gn_cat_unit(int Ca, int Cb, int G);
+int launch_gn_cat_finalize(const GnStats& sa, int Ga, int Ca, const GnStats& sb, int Gb, int Cb, float* out, int N, long HW, int G,
+                           hipStream_t s);
 int launch_layernorm(const half_t* x, long ldx, const float* gamma, const float* beta,
                      half_t* y, long ldy, long rows, int C, float eps, hipStream_t s);
 // stat[m * 2 + {0,1}] = sum, sum of squares of row m (the one-part form of IGemmParams::rowstat_out)

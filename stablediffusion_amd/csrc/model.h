@@ -38,11 +38,15 @@ struct VaeAttn {
 // output.  GroupNorm is invariant to the scale of its input up to eps, so norm1 / norm2 run with eps * s^2, conv1 /
 // conv2 emit s * (conv + bias), the shortcut (whose input carries s already) only scales its bias: the block computes the
 // same function, with every stored activation s times smaller.
+// out_buf / out_groups: where and at which granularity those summaries are written (default: the next ring slot, G
+// groups) -- a skip connection's live until the up path reads them, and an output that becomes the hidden half of a
+// concatenation is summarised over the sub-groups that concatenation's GroupNorm can merge (gn_cat_unit).
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
                 const float* tproj, int tproj_ld, const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr,
-                float stream_scale = 1.f);
+                float stream_scale = 1.f, GnStatBuf* out_buf = nullptr, int out_groups = 0);
 void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L,
-                 const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr);
+                 const GnStatBuf* x_stats = nullptr, GnStatBuf** out_stats = nullptr, GnStatBuf* out_buf = nullptr,
+                 int out_groups = 0);
 
 struct UNet {
     explicit UNet(const sd_unet_config& c);

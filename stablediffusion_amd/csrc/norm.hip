@@ -792,6 +792,88 @@ int launch_groupnorm(const half_t* x, long ldx, const float* gamma, const float*
     return 0;
 }
 
+// GroupNorm over a channel concatenation [A | B] (the up blocks' torch.cat([hidden, skip])) from the summaries the two
+// producers left: A's over Ga sub-groups of its Ca channels, B's over Gb of its Cb, every group of the concatenation a
+// union of whole sub-groups (gn_cat_unit).  One block per image, 32 lanes per group; the merge is the pivoted
+// weighted form of gn_apply2_kernel's: with p = the first summary's mean and n_k its element count,
+//   a = sum n_k (m_k - p),  b = sum n_k (m_k - p)^2,  q = sum M2_k,  n = sum n_k:  mean = p + a / n,  M2 = q + b - a^2 / n.
+// Output: one (mean, M2) per (image, group) = GnStats{out, 1, HW}; the apply pass then has one summary per group to read.
+struct GnCatSrc { const float* part; int S; long rows; int G; int C; };
+__global__ __launch_bounds__(1024) void gn_cat_finalize_kernel(GnCatSrc A, GnCatSrc B, float* __restrict__ out, long HW, int G) {
+    // 32 lanes per group, the summaries dealt round-robin; four loads per lane go out back to back (unconditional, on a
+    // clamped item: a first version with eight lanes per group and a plain loop took one round trip per summary, 8.9 us)
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int g = tid >> 5, pi = tid & 31;
+    const int cpg = (A.C + B.C) / G;
+    const int ua = A.C / A.G, ub = B.C / B.G;
+    const int gq = g < G ? g : G - 1;
+    const int c0 = gq * cpg, c1 = c0 + cpg;
+    // sub-group ranges of this group in either source
+    const int ca1 = c1 < A.C ? c1 : A.C;
+    const int a0 = c0 < A.C ? c0 / ua : 0, a1 = c0 < A.C ? (ca1 + ua - 1) / ua : 0;
+    const int b0 = c1 > A.C ? ((c0 > A.C ? c0 : A.C) - A.C) / ub : 0, b1 = c1 > A.C ? (c1 - A.C + ub - 1) / ub : 0;
+    const int wa = a1 - a0, wb = b1 - b0;
+    const int na = wa * A.S, nt = na + wb * B.S;
+    const float* pa = A.part + (long)n * A.S * A.G * 2;
+    const float* pb = B.part + (long)n * B.S * B.G * 2;
+    float pivot = 0.f;                 // item 0's mean: lane 0 of the group has it after the first batch of loads
+    float sa = 0.f, sb = 0.f, sq = 0.f, sn = 0.f;
+    for (int i0 = pi; i0 < nt + pi; i0 += 32 * 4) {      // (same trip count for all 32 lanes of a group: shuffles inside)
+        float2 v[4];
+        float cnt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ii = i0 + 32 * q;
+            const int i = ii < nt ? ii : nt - 1;
+            const bool isa = i < na;
+            const int j = isa ? i : i - na;
+            const int w = isa ? wa : wb;
+            const int k = j / w, sg = (isa ? a0 : b0) + j - k * w;
+            v[q] = *reinterpret_cast<const float2*>((isa ? pa : pb) + ((long)k * (isa ? A.G : B.G) + sg) * 2);
+            const long rws = isa ? A.rows : B.rows;
+            long rows = HW - (long)k * rws;
+            if (rows > rws) rows = rws;
+            cnt[q] = ii < nt ? (float)rows * (float)(isa ? ua : ub) : 0.f;
+        }
+        if (i0 == pi) pivot = __shfl(v[0].x, (tid & 32), 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = v[q].x - pivot;
+            sa += cnt[q] * d; sb += cnt[q] * d * d; sq += cnt[q] > 0.f ? v[q].y : 0.f; sn += cnt[q];
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); sq += __shfl_xor(sq, o, 64); sn += __shfl_xor(sn, o, 64);
+    }
+    if (pi == 0 && g < G) {
+        const float dm = sa / sn;
+        *reinterpret_cast<float2*>(out + ((long)n * G + g) * 2) = float2{pivot + dm, sq + sb - sa * dm};
+    }
+}
+
+// Width of the sub-groups a producer of Ca of the concatenation's Ca + Cb channels must summarise so that every one of
+// the G groups is a union of whole sub-groups (the seam included): gcd(channels per group, Ca).
+int gn_cat_unit(int Ca, int Cb, int G) {
+    int a = (Ca + Cb) / G, b = Ca;
+    while (b) { const int t = a % b; a = b; b = t; }
+    return a;
+}
+
+int launch_gn_cat_finalize(const GnStats& sa, int Ga, int Ca, const GnStats& sb, int Gb, int Cb, float* out, int N, long HW, int G,
+                           hipStream_t s) {
+    const int C = Ca + Cb;
+    if (G < 1 || G > 32 || C % G != 0 || Ga < 1 || Gb < 1 || Ca % Ga != 0 || Cb % Gb != 0 || !sa.part || !sb.part) {
+        set_error("gn_cat_finalize: bad arguments"); return 1;
+    }
+    const int cpg = C / G, ua = Ca / Ga, ub = Cb / Gb;
+    if (gn_cat_unit(Ca, Cb, G) % ua != 0 || cpg % ub != 0 || Ca % ub != 0) { set_error("gn_cat_finalize: sub-groups straddle a group boundary"); return 1; }
+    GnCatSrc A{sa.part, sa.S, sa.rows, Ga, Ca}, B{sb.part, sb.S, sb.rows, Gb, Cb};
+    hipLaunchKernelGGL(gn_cat_finalize_kernel, dim3(N), dim3(1024), 0, s, A, B, out, HW, G);
+    SD_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_gn_stats(const half_t* x, long ldx, int N, long HW, int C, int G, float* scratch, GnStats* st, hipStream_t s) {
     if (C % 8 != 0 || C % G != 0 || G > 256) { set_error("groupnorm: C must be a multiple of 8 and of groups"); return 1; }
     const int S = gn_slabs(N, HW, C, G);

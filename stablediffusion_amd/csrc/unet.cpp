@@ -6,6 +6,8 @@
 // NHWC fp16 activations, skip connections written straight into the concatenation buffers of the
 // up path (no torch.cat copies), fused qkv / GEGLU / residual / time-embedding epilogues, one
 // stacked GEMV for all 22 time_emb_proj layers, and a stack-discipline workspace arena.
+#include <vector>
+
 #include "model.h"
 #include <cmath>
 #include <cstdlib>
@@ -254,7 +256,8 @@ int UNet::finalize() {
 
 // ------------------------------------------------------------------------------------------ blocks
 void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, int G, float eps,
-                const float* tproj, int tproj_ld, const GnStatBuf* x_stats, GnStatBuf** out_stats, float stream_scale) {
+                const float* tproj, int tproj_ld, const GnStatBuf* x_stats, GnStatBuf** out_stats, float stream_scale,
+                GnStatBuf* out_buf, int out_groups) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const long M = (long)N * H * W;
@@ -276,8 +279,8 @@ void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, 
         op_conv(c, r.sc, x, N, H, W, res, 1, 0, nullptr, 0, nullptr, 0, -1, 0, s != 1.f ? &fs : nullptr);
     }
     ConvFuse f2;
-    f2.gn_out = (out_stats && gn_wants_stats(HW, r.cout, G)) ? ctx_gnbuf(c) : nullptr;
-    f2.gn_groups = G;
+    f2.gn_out = (out_stats && gn_wants_stats(HW, r.cout, G)) ? (out_buf ? out_buf : ctx_gnbuf(c)) : nullptr;
+    f2.gn_groups = out_groups > 0 ? out_groups : G;
     f2.acc_scale = s; f2.bias_scale = s;
     op_gn_conv(c, r.n2, r.c2, h2, N, H, W, out, G, eps_s, 1, f1.gn_out, nullptr, 0, &res, &f2);
     if (out_stats) *out_stats = f2.gn_out;
@@ -285,7 +288,7 @@ void run_resnet(Ctx& c, const Resnet& r, View x, int N, int H, int W, View out, 
 }
 
 void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out, int G, View text_kv, int L,
-                 const GnStatBuf* x_stats, GnStatBuf** out_stats) {
+                 const GnStatBuf* x_stats, GnStatBuf** out_stats, GnStatBuf* out_buf, int out_groups) {
     Arena& a = *c.arena;
     const size_t mk = a.mark();
     const int C = t.C;
@@ -351,8 +354,8 @@ void run_xformer(Ctx& c, const Xformer& t, View x, int N, int H, int W, View out
         View tmp = cur; cur = nxt; nxt = tmp;
     }
     ConvFuse fo;
-    fo.gn_out = (out_stats && gn_wants_stats(T, C, G)) ? ctx_gnbuf(c) : nullptr;
-    fo.gn_groups = G;
+    fo.gn_out = (out_stats && gn_wants_stats(T, C, G)) ? (out_buf ? out_buf : ctx_gnbuf(c)) : nullptr;
+    fo.gn_groups = out_groups > 0 ? out_groups : G;
     op_conv(c, t.pout, cur, N, H, W, out, 1, 0, nullptr, 0, &x, 0, -1, 0, &fo);
     if (out_stats) *out_stats = fo.gn_out;
     a.release(mk);
@@ -452,6 +455,18 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     //      it (big maps only); `xs` = those of the current x, nullptr when nobody produced them ----
     ctx_gnpool_init(c, B, (long)H * W, G);
     GnStatBuf* xs = nullptr;
+    // A skip connection's summaries are read twice: by the next layer of the down path and, much later, by the up block
+    // that concatenates it -- they get buffers of their own instead of ring slots.  `hid` receives those of a tensor that
+    // becomes the HIDDEN half of a concatenation, over the sub-groups gn_cat_unit prescribes (up to 128 of them).
+    std::vector<GnStatBuf> sst((size_t)nskip);
+    GnStatBuf hid;
+    if (c.gnpool[0].buf) {
+        for (auto& b : sst) b.buf = a.alloc_f(gnstat_floats(B, (long)H * W, G));
+        hid.buf = a.alloc_f(gnstat_floats(B, (long)H * W, 128));
+    }
+    auto skip_stat = [&](int si, long HWs, int C) -> GnStatBuf* {
+        return (sst[(size_t)si].buf && gn_wants_stats(HWs, C, G)) ? &sst[(size_t)si] : nullptr;
+    };
 
     // ---- conv_in: one launch straight from the NCHW latents (edge.hip); otherwise (inpainting's 9 channels, odd maps)
     //      im2col into a 64-wide K, then the GEMM kernel ----
@@ -459,7 +474,7 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     {
         const size_t mk = a.mark();
         const long M = (long)B * H * W;
-        GnStatBuf* gb = gn_wants_stats((long)H * W, boc[0], G) ? ctx_gnbuf(c) : nullptr;
+        GnStatBuf* gb = skip_stat(skip_i, (long)H * W, boc[0]);
         const View y0 = skip_view(skip_i);
         HeadParams hp;
         hp.x_nchw = sample; hp.w = conv_in.w; hp.K = conv_in.K; hp.bias = conv_in.bias; hp.y = y0.p; hp.ldy = y0.ld;
@@ -500,20 +515,20 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
                 GnStatBuf* rs = nullptr;
                 run_resnet(c, r, x, B, h, w, tmp, G, eps, tproj, temb_total, xs, &rs);
                 View dst = skip_view(skip_i);
-                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, &xs);
+                run_xformer(c, down_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, &xs, skip_stat(skip_i, (long)h * w, r.cout));
                 a.release(mk);
                 x = dst;
             } else {
                 View dst = skip_view(skip_i);
-                run_resnet(c, r, x, B, h, w, dst, G, eps, tproj, temb_total, xs, &xs);
+                run_resnet(c, r, x, B, h, w, dst, G, eps, tproj, temb_total, xs, &xs, 1.f, skip_stat(skip_i, (long)h * w, r.cout));
                 x = dst;
             }
             ++skip_i;
         }
         if (i != nb - 1) {
-            View dst = skip_view(skip_i++);
             ConvFuse f;
-            f.gn_out = gn_wants_stats((long)(h / 2) * (w / 2), down_ds[i].cout, G) ? ctx_gnbuf(c) : nullptr;
+            f.gn_out = skip_stat(skip_i, (long)(h / 2) * (w / 2), down_ds[i].cout);
+            View dst = skip_view(skip_i++);
             f.gn_groups = G;
             op_conv(c, down_ds[i], x, B, h, w, dst, 2, 0, nullptr, 0, nullptr, 0, -1, 0, &f);
             xs = f.gn_out;
@@ -538,6 +553,14 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
     // ---- up path ----
     View final_x;
     int k = 0;
+    // Summaries of the hidden half of cats[k], when its producer (the previous layer's last convolution or the upsample
+    // convolution) left them, and over how many sub-groups.  Off unless SD_GN_CAT=1: measured a wash on the C2 forward
+    // (10.07-10.13 ms with, 10.04-10.10 without, alternating runs on one box: the statistics passes it removes, five
+    // launches, cost about what the five producers' extra epilogue work and the merge launches cost --
+    // profiles/r03_groupnorm_apply.txt); every concatenation's norm1 then runs its own statistics pass.
+    const GnStatBuf* hid_ready = nullptr;
+    int hid_groups = 0;
+    static const bool no_cat_stats = getenv("SD_GN_CAT") == nullptr;
     for (int i = 0; i < nb; ++i) {
         for (int j = 0; j < cfg.layers_per_block + 1; ++j, ++k) {
             const Cat& ct = cats[(size_t)k];
@@ -554,16 +577,48 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
             } else {
                 dst = View(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
             }
-            // the input is a concatenation [hidden | skip] written by two producers (its groups can straddle
-            // the seam): norm1 computes its own statistics; the tail's GroupNorm gets the last layer's
+            // The input is a concatenation [hidden | skip] written by two producers.  On the big maps both left summaries
+            // (the hidden half's over sub-groups narrow enough that no group of the concatenation straddles one:
+            // gn_cat_unit): one small launch merges them per group and norm1 runs its apply pass only.  Otherwise norm1
+            // computes its own statistics.
+            const long HWc = (long)h * w;
+            const int Ccat = ct.c1 + ct.c2, si = nskip - 1 - k;
+            GnStatBuf catst;
+            const GnStatBuf* xin_stats = nullptr;
+            if (!no_cat_stats && hid_ready && hid_ready->st.part && sst[(size_t)si].st.part && gn_wants_stats(HWc, Ccat, G) &&
+                ct.c2 % G == 0 && (Ccat / G) % (ct.c2 / G) == 0 && ct.c1 % (ct.c2 / G) == 0) {
+                float* fin = a.alloc_f((long)B * G * 2);
+                if (go && !c.err) {
+                    prof_open(s, "gn_cat_finalize_kernel", 0.0, 8.0 * B * (hid_ready->st.S * hid_groups + sst[(size_t)si].st.S * G));
+                    c.err = launch_gn_cat_finalize(hid_ready->st, hid_groups, ct.c1, sst[(size_t)si].st, G, ct.c2, fin, B, HWc, G, s);
+                    prof_close(s);
+                }
+                catst.buf = fin;
+                catst.st.part = fin; catst.st.S = 1; catst.st.rows = HWc;
+                xin_stats = &catst;
+            }
+            hid_ready = nullptr;
+            // what the NEXT concatenation's norm1 needs from this layer's output (or from the upsample convolution after it)
+            int nx_groups = 0;
+            if (!last && hid.buf && !no_cat_stats) {
+                const Cat& nx = cats[(size_t)k + 1];
+                const int u = gn_cat_unit(nx.c1, nx.c2, G);
+                if (gn_wants_stats(last_in_block ? HWc * 4 : HWc, nx.c1 + nx.c2, G) && (u >= 8 || u == 4) && nx.c1 / u <= 128) nx_groups = nx.c1 / u;
+            }
+            const bool hid_here = nx_groups > 0 && !last_in_block;       // this layer's last convolution writes the hidden half
+            GnStatBuf* outp = nullptr;
             xs = nullptr;
             if (cfg.up_block_has_attn[i]) {
                 View tmp(a.alloc_h((long)B * h * w * r.cout), r.cout, r.cout);
                 GnStatBuf* rs = nullptr;
-                run_resnet(c, r, xin, B, h, w, tmp, G, eps, tproj, temb_total, nullptr, &rs);
-                run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, last ? &xs : nullptr);
+                run_resnet(c, r, xin, B, h, w, tmp, G, eps, tproj, temb_total, xin_stats, &rs);
+                if (last) run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, &xs);
+                else if (hid_here) run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, &outp, &hid, nx_groups);
+                else run_xformer(c, up_att[i][j], tmp, B, h, w, dst, G, text_kv, L, rs, nullptr);
             } else {
-                run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total, nullptr, last ? &xs : nullptr);
+                if (last) run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total, xin_stats, &xs);
+                else if (hid_here) run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total, xin_stats, &outp, 1.f, &hid, nx_groups);
+                else run_resnet(c, r, xin, B, h, w, dst, G, eps, tproj, temb_total, xin_stats, nullptr);
             }
             if (last) {
                 final_x = dst;   // the temporary stays alive for the tail
@@ -571,9 +626,15 @@ int UNet::run(Ctx& c, const half_t* sample, const float* timesteps, const half_t
                 if (last_in_block) {
                     const Cat& nx = cats[(size_t)k + 1];
                     View up_dst(nx.p, nx.c1 + nx.c2, nx.c1);
-                    op_conv(c, up_us[i], dst, B, h, w, up_dst, 1, 1);
+                    ConvFuse fu;
+                    fu.gn_out = nx_groups > 0 ? &hid : nullptr;
+                    fu.gn_groups = nx_groups;
+                    op_conv(c, up_us[i], dst, B, h, w, up_dst, 1, 1, nullptr, 0, nullptr, 0, -1, 0, nx_groups > 0 ? &fu : nullptr);
+                    outp = fu.gn_out;
                     h *= 2; w *= 2;
                 }
+                hid_ready = outp;
+                hid_groups = nx_groups;
                 a.release(mk);
             }
         }

@@ -663,3 +663,27 @@ def test_unet_conv_out_one_launch(engine_lib, N, H, W, Cout, silu):
     ring = torch.ones(H, W, dtype=torch.bool)
     ring[1:-1, 1:-1] = False
     assert rel_l2(out[:, :, ring], ref[:, :, ring]) < 4e-3
+
+
+@pytest.mark.parametrize("N,HW,Ca,Cb", [(8, 4096, 640, 320), (2, 4096, 320, 320), (2, 1024, 1280, 640), (2, 1024, 640, 640),
+                                        (3, 1024, 640, 320), (2, 1280, 640, 320)])
+def test_groupnorm_of_a_concatenation_from_the_halves_summaries(engine_lib, N, HW, Ca, Cb):
+    """The up blocks' norm1 over torch.cat([hidden, skip]): per-half summaries (the hidden half over sub-groups of width
+    gcd(C / 32, Ca): 960 = 640 + 320 has a group that straddles the seam) merged by gn_cat_finalize_kernel, then the apply
+    pass -- against F.group_norm of the concatenated tensor.  The last case has a ragged last slab."""
+    G = 32
+    Cc = Ca + Cb
+    g = torch.Generator().manual_seed(HW + Ca)
+    x = torch.randn(N, HW, Cc, generator=g) * (0.5 + torch.rand(1, 1, Cc, generator=g) * 2) + torch.randn(1, 1, Cc, generator=g) * 3
+    x[..., Ca:] += 5.0                                      # the halves sit at different levels: a straddling group sees both
+    x = x.half()
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.2 * torch.randn(Cc, generator=g)
+    ref = F.silu(F.group_norm(x.float().permute(0, 2, 1), G, gamma, beta, 1e-5)).permute(0, 2, 1)
+    xd, gd, bd = h(x), gamma.cuda(), beta.cuda()
+    y = torch.zeros_like(xd)
+    rc = engine_lib.sd_op_groupnorm_concat(P(xd), Ca, Cb, P(gd), P(bd), P(y), N, HW, G, 1e-5, 1, stream())
+    assert rc == 0, engine_lib.sd_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
+    assert (y.float().cpu() - ref).abs().max() < 2e-2
