@@ -128,8 +128,8 @@ def rocprof_avg_us_for(function: str):
 
 
 KERNEL_FAMILIES = (("conv/GEMM", ("igemm2_kernel", "conv3x3_halo_kernel", "igemm_kernel", "wsgemm_kernel", "geglu_persist_kernel",
-                                  "ffn_fused_kernel")), ("attention", ("attn_kernel",)),
-                   ("norms", ("groupnorm", "layernorm", "row_stats")))
+                                  "ffn_fused_kernel", "conv_head_kernel", "conv_tail_kernel")), ("attention", ("attn_kernel",)),
+                   ("norms", ("groupnorm", "layernorm", "row_stats", "gn_cat_finalize_kernel")))
 
 
 def kernel_function(row_name: str) -> str:
