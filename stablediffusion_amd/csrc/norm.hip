@@ -605,7 +605,10 @@ __global__ __launch_bounds__(T) void gn_fused_kernel(const half_t* __restrict__ 
 // unit (channels per fused block) or 0 when the fused form does not apply
 inline int gn_fused_unit(long HW, int C, int G) {
     const int cpg = C / G;
-    if (HW > 1024 || cpg < 8 || (cpg & 1)) return 0;
+    // 32 x 32 maps: the statistics + apply pair is never slower than the single kernel since round 3's apply kernel
+    // (C = 960: 15.9 vs 25.6 us, 1920: 23.5 vs 28.8, 640: 15.2 vs 15.4), so the single-kernel form is for HW <= 512
+    static const long hw_max = getenv("SD_GN_FUSED_MAX_HW") ? atol(getenv("SD_GN_FUSED_MAX_HW")) : 512;
+    if (HW > hw_max || cpg < 8 || (cpg & 1)) return 0;
     int unit = cpg;
     while (unit % 8 != 0) unit += cpg;
     if (unit / cpg > 4 || unit > C || C % unit != 0) return 0;
