@@ -232,6 +232,11 @@ int sd_prof_collect(sd_prof_entry* out, int max_entries, int* n_entries);
  * 16-byte-per-lane copy of `bytes` (choose > 256 MiB to pass the Infinity Cache) -> GB/s, read + write. */
 int sd_probe_mfma(int iters, float* tflops, void* stream);
 int sd_probe_copy(int64_t bytes, int iters, float* gbs, void* stream);
+/* L2 -> LDS rate of the LDS-DMA path (buffer_load ... lds) with every CU streaming, the operand path of the GEMM kernels:
+ * each block (one per CU, four waves) walks `region_bytes` (a multiple of 4096) `passes` times with `depth` 1-KiB pieces
+ * outstanding per wave (1, 2, 4, 8, 16 or 32); shared bit 0: all blocks walk the same region (a weight operand), else each its
+ * own (an activation operand); shared bit 1: the same walk with ordinary 16-byte loads into registers.  *gbs = aggregate GB/s.  DESIGN.md section 4 reads the GEMM family's ceiling against it. */
+int sd_probe_lds_dma(int64_t region_bytes, int passes, int depth, int shared, float* gbs, void* stream);
 
 /* Tuner / test hook: force the LDS-DMA conv kernel's tile variant (0..5) and split-K factor for
  * every following launch; variant -1 restores the built-in per-shape choice. */

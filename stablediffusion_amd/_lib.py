@@ -115,6 +115,7 @@ SIGNATURES = {
     "sd_cfg_linear_step": (_I, [_P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _P]),
     "sd_igemm_force": (_I, [_I, _I]),
     "sd_probe_mfma": (_I, [_I, C.POINTER(_F), _P]),
+    "sd_probe_lds_dma": (_I, [_I64, _I, _I, _I, C.POINTER(_F), _P]),
     "sd_probe_copy": (_I, [_I64, _I, C.POINTER(_F), _P]),
     "sd_prof_enable": (_I, [_I]),
     "sd_prof_collect": (_I, [C.POINTER(SdProfEntry), _I, C.POINTER(_I)]),

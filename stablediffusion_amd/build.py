@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsd_engine.so")
-SOURCES = ["igemm.hip", "igemm2.hip", "wsgemm.hip", "pgemm.hip", "ffn.hip", "edge.hip", "norm.hip", "attention.hip", "misc.hip", "probe.hip", "runtime.cpp", "unet.cpp", "vae.cpp", "clip.cpp", "capi.cpp"]
+SOURCES = ["igemm.hip", "igemm2.hip", "igemm3.hip", "wsgemm.hip", "pgemm.hip", "ffn.hip", "edge.hip", "norm.hip", "attention.hip", "misc.hip", "probe.hip", "runtime.cpp", "unet.cpp", "vae.cpp", "clip.cpp", "capi.cpp"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 

@@ -242,6 +242,10 @@ int sd_probe_mfma(int iters, float* tflops, void* stream) {
     if (iters < 1 || !tflops) { set_error("sd_probe_mfma: bad arguments"); return SD_ERR_INVALID; }
     return probe_mfma(iters, tflops, static_cast<hipStream_t>(stream));
 }
+int sd_probe_lds_dma(int64_t region_bytes, int passes, int depth, int shared, float* gbs, void* stream) {
+    if (!gbs) { set_error("sd_probe_lds_dma: bad arguments"); return SD_ERR_INVALID; }
+    return probe_dma((long)region_bytes, passes, depth, shared, gbs, static_cast<hipStream_t>(stream));
+}
 int sd_probe_copy(int64_t bytes, int iters, float* gbs, void* stream) {
     if (bytes < 4096 || iters < 1 || !gbs) { set_error("sd_probe_copy: bad arguments"); return SD_ERR_INVALID; }
     return probe_copy((long)bytes, iters, gbs, static_cast<hipStream_t>(stream));

@@ -1214,8 +1214,8 @@ static const char* kIgemm2Names[] = {
     "conv3x3_halo_kernel<160>",
     "igemm2_kernel<128,80,4,1,2,%s,false,64>", "igemm2_kernel<128,80,4,1,3,%s,false,64>",
     "wsgemm_kernel<160,false,...>", "wsgemm_kernel<128,true,...>", "conv3x3_halo_kernel<128>",
-    "igemm2_kernel<128,80,4,1,4,%s,false,64>", "igemm2_kernel<128,80,4,1,5,%s,false,64>"};
-constexpr int kNumVariants = 18;
+    "igemm2_kernel<128,80,4,1,4,%s,false,64>", "igemm2_kernel<128,80,4,1,5,%s,false,64>", "igemm3_kernel"};
+constexpr int kNumVariants = 19;
 
 void igemm2_force(int variant, int splits) { g_force_variant = variant; g_force_splits = splits; }
 
@@ -1229,7 +1229,7 @@ bool igemm2_supported(const IGemmParams& p) {
 static void tile_dims(int v, int* bm, int* bn) {
     static const int dims[kNumVariants][2] = {{256, 128}, {128, 128}, {128, 160}, {128, 64}, {64, 64}, {256, 160}, {256, 128}, {256, 160},
                                                {128, 64}, {128, 160}, {256, 160}, {128, 80}, {128, 80}, {128, 80}, {128, 128}, {256, 128},
-                                               {128, 80}, {128, 80}};
+                                               {128, 80}, {128, 80}, {128, 80}};
     *bm = dims[v][0]; *bn = dims[v][1];
 }
 
@@ -1399,8 +1399,18 @@ int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s) {
         case 9: return launch_v2<128, 160, 2, 2, 3>(p, partial, sp, s);
         case 10: return launch_halo<160>(p, partial, sp, s);
         case 15: return launch_halo<128>(p, partial, sp, s);
-        case 11: return launch_v2<128, 80, 4, 1, 2>(p, partial, sp, s);
-        case 12: return launch_v2<128, 80, 4, 1, 3>(p, partial, sp, s);
+        case 11:
+        case 12:
+        case 18:
+            // 18 = igemm3_kernel (activation operand through the ordinary load path instead of the LDS-DMA ring) asked for by
+            // name (tests, tuner), falling back to the 3-stage DMA tile for problems it does not take
+            {
+                static const bool g3_auto = getenv("SD_IGEMM3") != nullptr;        // off by default: measured not faster (igemm3.hip)
+                if (sp <= 1 && (v == 18 || (g3_auto && g_force_variant.load() < 0)) && igemm3_supported(p))
+                    return launch_igemm3(p, weights_outweigh_activations(p), s);
+            }
+            if (v == 11) return launch_v2<128, 80, 4, 1, 2>(p, partial, sp, s);
+            return launch_v2<128, 80, 4, 1, 3>(p, partial, sp, s);
         case 16: return launch_v2<128, 80, 4, 1, 4>(p, partial, sp, s);
         case 17: return launch_v2<128, 80, 4, 1, 5>(p, partial, sp, s);
         case 13:

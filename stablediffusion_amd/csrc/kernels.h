@@ -84,6 +84,10 @@ const char* igemm2_name(int variant);
 long igemm2_partial_floats(const IGemmParams& p);      // fp32 workspace needed for split-K (0 if none)
 int launch_igemm2(const IGemmParams& p, float* partial, hipStream_t s);
 void igemm2_force(int variant, int splits);            // tuner / tests: -1 restores the heuristic
+// Pointwise 128 x 80 tile with the activation operand fetched straight into registers (igemm3.hip): launch_igemm2 takes
+// it instead of the 128 x 80 LDS-DMA variants when the problem allows (no split-K, GEGLU, row add, GroupNorm summaries).
+bool igemm3_supported(const IGemmParams& p);
+int launch_igemm3(const IGemmParams& p, int mfast, hipStream_t s);
 // Rows the packed weight matrix must be padded to (zero rows), so tile loads need no masks.
 constexpr int kWeightRowPad = 256;
 // Weight-stationary persistent GEMM for the K = 320 pointwise problems of the 64x64 level (wsgemm.hip):
@@ -239,5 +243,7 @@ int launch_cfg_ddim(const half_t* eps2b, half_t* lat, long n, float g, float cx,
 // Box probe (probe.hip): back-to-back 16x16x32 f16 MFMA loop (TFLOP/s) and a 16-byte-per-lane copy (GB/s, read + write)
 int probe_mfma(int iters, float* tflops, hipStream_t s);
 int probe_copy(long bytes, int iters, float* gbs, hipStream_t s);
+// L2 -> LDS rate of the LDS-DMA path with every CU streaming (probe.hip); aggregate GB/s over all CUs
+int probe_dma(long region_bytes, int passes, int depth, int shared, float* gbs, hipStream_t s);
 
 }  // namespace sd

@@ -42,6 +42,60 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const f4* __restrict__ 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// L2 -> LDS streaming rate of the LDS-DMA path (buffer_load ... lds, 1 KiB per wave instruction) with EVERY CU
+// streaming, as the GEMM kernels' operand rings do: `region` bytes per block are walked `passes` times by the block's
+// four waves with `depth` pieces outstanding per wave; shared bit 0: all blocks walk the SAME region (the weight operand),
+// else block b walks its own (the activation operand); shared bit 1: ordinary loads into registers instead of LDS-DMA.
+// Nothing reads the LDS; the pieces overwrite a small ring.
+__global__ __launch_bounds__(256) void probe_dma_kernel(const half_t* __restrict__ src, long region, int passes, int depth, int shared,
+                                                        float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const half_t* base = src + ((shared & 1) ? 0 : (long)blockIdx.x * (region / 2));
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(base), 0, (int)region, 0x00020000);
+    const int pieces = (int)(region / 1024);                 // 1 KiB pieces of the region
+    const int per_wave = pieces / 4;
+    int slot = 0;
+    if (shared >= 2) {
+        // the same walk through the ordinary vector-memory path (16 bytes per lane into registers), eight loads in flight
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ps = 0; ps < passes; ++ps) {
+            for (int i = 0; i + 8 <= per_wave; i += 8) {
+                f4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    v[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(((long)((i + q) * 4 + wave)) * 1024 + lane * 16), 0, 0));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];
+            }
+        }
+        if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e-30f) sink[0] = acc[0];
+        return;
+    }
+    for (int ps = 0; ps < passes; ++ps) {
+        for (int i = 0; i < per_wave; ++i) {
+            const unsigned off = (unsigned)(((long)(i * 4 + wave)) * 1024 + lane * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + (wave * 32 + slot) * 1024), 16, off, 0, 0, 0);
+            if (++slot == 32) slot = 0;
+            // keep `depth` pieces in flight: wait until at most depth - 1 are outstanding before the next issue
+            switch (depth) {
+                case 1: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (reinterpret_cast<float*>(smem)[tid] == 1.2345e-30f) sink[0] = 1.f;     // never true
+#endif
+}
+
 }  // namespace
 
 int probe_mfma(int iters, float* tflops, hipStream_t s) {
@@ -87,6 +141,35 @@ int probe_copy(long bytes, int iters, float* gbs, hipStream_t s) {
     (void)hipFree(src); (void)hipFree(dst);
     if (e != hipSuccess) { set_error(hipGetErrorString(e)); return 3; }
     *gbs = (float)(2.0 * (double)n * 16.0 * iters / (ms * 1e-3) / 1e9);
+    return 0;
+}
+
+int probe_dma(long region, int passes, int depth, int shared, float* gbs, hipStream_t s) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (region < 4096 || region % 4096 != 0 || region >= (1L << 31) || passes < 1) { set_error("probe_dma: bad arguments"); return 1; }
+    const long total = (shared & 1) ? region : region * cus;
+    half_t* src = nullptr;
+    float* sink = nullptr;
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&src), (size_t)total));
+    SD_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sink), 256));
+    (void)hipMemsetAsync(src, 1, (size_t)total, s);
+    const int lds = 4 * 32 * 1024;
+    SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe_dma_kernel, dim3(cus), dim3(256), lds, s, src, region, 1, depth, shared, sink);      // warm-up: fills L2 / MALL
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(probe_dma_kernel, dim3(cus), dim3(256), lds, s, src, region, passes, depth, shared, sink);
+    (void)hipEventRecord(e1, s);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(sink);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return 3; }
+    *gbs = (float)((double)region * passes * cus / (ms * 1e-3) / 1e9);
     return 0;
 }
 

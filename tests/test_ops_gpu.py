@@ -687,3 +687,34 @@ def test_groupnorm_of_a_concatenation_from_the_halves_summaries(engine_lib, N, H
     torch.cuda.synchronize()
     assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
     assert (y.float().cpu() - ref).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("M,Cin,Cout,bias,res", [(2048, 1280, 1280, True, True), (8192, 640, 640, False, False), (2048, 5120, 1280, True, True),
+                                                 (1000, 256, 200, True, True), (130, 320, 88, True, False), (512, 1280, 3840, False, False)])
+def test_pointwise_gemm_activations_through_registers(engine_lib, M, Cin, Cout, bias, res):
+    """igemm3_kernel (variant 18): the 128 x 80 pointwise tile whose activation fragments are fetched straight into registers
+    (only the weights use the LDS-DMA ring) against F.linear in fp32; ragged M and N, with and without bias / residual."""
+    g = torch.Generator().manual_seed(M + Cout)
+    x = torch.randn(M, Cin, generator=g).half()
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).half()
+    b = torch.randn(Cout, generator=g) * 0.5 if bias else None
+    r = torch.randn(M, Cout, generator=g).half() if res else None
+    ref = F.linear(x.float(), w.float(), b)
+    if r is not None:
+        ref = ref.half().float() + r.float()
+    y = torch.zeros(M, Cout, dtype=torch.float16, device="cuda")
+    xd, wd = h(x), h(w)
+    bd = b.cuda() if b is not None else None
+    rd = h(r) if r is not None else None
+    engine_lib.sd_igemm_force(18, 1)
+    try:
+        rc = engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, P(rd), P(y), 1, M, 1, Cin, Cout, 1, 1, 0, 0, stream())
+        assert rc == 0, engine_lib.sd_last_error()
+        torch.cuda.synchronize()
+        y2 = torch.zeros_like(y)                 # twice on the same buffers: a race in the fragment ring would not repeat bit for bit
+        engine_lib.sd_op_conv2d(P(xd), P(wd), P(bd), None, P(rd), P(y2), 1, M, 1, Cin, Cout, 1, 1, 0, 0, stream())
+        torch.cuda.synchronize()
+    finally:
+        engine_lib.sd_igemm_force(-1, 0)
+    assert rel_l2(y, ref) < 2e-3, rel_l2(y, ref)
+    assert torch.equal(y, y2)
