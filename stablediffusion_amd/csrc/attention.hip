@@ -468,6 +468,11 @@ int launch_attention(const half_t* q, const half_t* k, const half_t* v, half_t* 
     static const int nwv = getenv("SD_ATTN_NWV") ? atoi(getenv("SD_ATTN_NWV")) : 8;
     if (d == 40 && prescaled && !causal && nwv == 8 && (long)cdiv(Tq, 512) * B * heads >= 512)
         return launch_attn<40, 4, 64, true, 8>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, true, s);
+    // d = 80 (the 32 x 32 level): 256 queries per block where that still gives one block per CU -- 42.5 -> 36.9 us on the
+    // 1024-token self-attention; d = 64 (SDXL) measured slower with eight waves (259.6 -> 269.8, 42.5 -> 48.3 us) and stays at four
+    static const int nwv80 = getenv("SD_ATTN_NWV80") ? atoi(getenv("SD_ATTN_NWV80")) : 8;
+    if (nwv80 == 8 && !causal && d == 80 && (long)cdiv(Tq, 256) * B * heads >= 256)
+        return launch_attn<80, 2, 64, false, 8>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, prescaled != 0, s);
     if (d == 160 && (long)cdiv(Tq, 128) * B * heads < 256)
         return launch_attn<160, 1, 64, false>(q, k, v, out, B, Tq, Tk, heads, ldq, ldk, ldv, ldo, causal, prescaled != 0, s);
     switch (d) {
