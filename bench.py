@@ -202,12 +202,19 @@ def box_probe(lib, stream=None):
     (VERDICT r2 item 2): ~40 ms of back-to-back v_mfma_f32_16x16x32_f16 on register operands (dense fp16
     TFLOP/s the box sustains, random operands) and a 16-byte-per-lane copy of 512 MiB -> 512 MiB (GB/s read +
     write, beyond the Infinity Cache).  `value / box_probe.mfma_tflops` compares rounds across boxes."""
-    tf, gb = C.c_float(), C.c_float()
+    tf, gb, d1, d2 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
     _lib.check(lib.sd_probe_mfma(300000, C.byref(tf), None), "sd_probe_mfma")
     _lib.check(lib.sd_probe_copy(512 << 20, 5, C.byref(gb), None), "sd_probe_copy")
+    # the operand path of the GEMM kernels (round 3): every CU streaming through the LDS-DMA path, a region all blocks
+    # share (weights, L2-resident) and a region per block that overflows L2 into the Infinity Cache (activations)
+    _lib.check(lib.sd_probe_lds_dma(1 << 20, 64, 4, 1, C.byref(d1), None), "sd_probe_lds_dma")
+    _lib.check(lib.sd_probe_lds_dma(1 << 20, 64, 4, 0, C.byref(d2), None), "sd_probe_lds_dma")
     return {"mfma_tflops": round(tf.value, 1), "hbm_gbs": round(gb.value, 1),
+            "l2_to_lds_shared_gbs": round(d1.value, 1), "l2_to_lds_own_gbs": round(d2.value, 1),
             "what": "sd_probe_mfma: 300000 x 16 v_mfma_f32_16x16x32_f16 per wave, 4 waves per CU, random operands; "
-                    "sd_probe_copy: 5 x (512 MiB -> 512 MiB) float4 copy, read + write bytes"}
+                    "sd_probe_copy: 5 x (512 MiB -> 512 MiB) float4 copy, read + write bytes; sd_probe_lds_dma: every CU "
+                    "streaming 1 MiB regions 64 times through buffer_load ... lds, 4 pieces in flight per wave, one region "
+                    "for all blocks (shared) / one per block (own)"}
 
 
 def usable_cores() -> int:
