@@ -413,3 +413,25 @@ def test_force_upcast_vae_encode_beyond_fp16_range(engine_lib):
     engine_lib.sd_vae_encode_range_shift(plain._h, 8)
     b = plain.encode_moments(img.cuda())
     assert plain._enc_shift == 0 and rel_l2(b[:, :4], a[:, :4]) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 32, 48), (1, 64, 64), (2, 64, 64), (5, 24, 40)])
+def test_sd15_unet_odd_batches_and_non_square_maps(engine_lib, B, H, W):
+    """Full-width SD1.5 UNet off the benchmark's shapes: the kernels with shape conditions (the fused feed-forward needs
+    >= 64 blocks of 128 rows, conv_in 128-pixel tiles inside one image, the conv_out tail 8 x 16 pixel tiles, the halo
+    kernels a 256-pixel patch, the tuned tile table the benchmark's M x N x K) must fall back, not mis-index: odd batch,
+    48- / 40-wide maps (16-wide patches; 24 x 40: no 128-pixel tile, no 256-pixel patch at the lower levels), batch 1 and
+    2 at 64 x 64 (the fused feed-forward's threshold from both sides)."""
+    cfg = config.sd15_unet()
+    sd = weights.synth_state_dict(weights.unet_manifest(cfg), seed=43, dtype=torch.float16, perturb=0.1)
+    net = HipUNet2DConditionModel(cfg).load_state_dict(sd)
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.randn(B, 4, H, W, generator=g).half()
+    ehs = torch.randn(B, 77, 768, generator=g).half()
+    t = torch.tensor(77.0)
+    got = net(x.cuda(), t, ehs.cuda())[0]
+    ref = oracle_unet_on_gpu(cfg, sd, x, t, ehs)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < TOL, rel_l2(got, ref)
+    again = net(x.cuda(), t, ehs.cuda())[0]                  # same shapes -> bitwise the same (no atomics, fixed orders)
+    assert torch.equal(got, again)
