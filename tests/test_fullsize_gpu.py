@@ -435,3 +435,26 @@ def test_sd15_unet_odd_batches_and_non_square_maps(engine_lib, B, H, W):
     assert rel_l2(got, ref) < TOL, rel_l2(got, ref)
     again = net(x.cuda(), t, ehs.cuda())[0]                  # same shapes -> bitwise the same (no atomics, fixed orders)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("B,h,w", [(3, 24, 40), (1, 40, 56), (5, 16, 16)])
+def test_sd15_vae_odd_batches_and_non_square_maps(engine_lib, B, h, w):
+    """Full-width SD1.5 VAE decode + encode off the benchmark's shapes (192 x 320, 320 x 448, 128 x 128 px; odd batches):
+    statistics slabs that do not divide the map, halo patches of every width, the upsample-fused convolutions and the
+    3-channel conv_out on maps the tuned table has no row for."""
+    cfg = config.sd15_vae()
+    sd = weights.synth_state_dict(weights.vae_manifest(cfg), seed=44, dtype=torch.float16, perturb=0.1)
+    vae = HipAutoencoderKL(cfg).load_state_dict(sd)
+    z = (torch.randn(B, 4, h, w, generator=torch.Generator().manual_seed(h * w)) * 1.5).half()
+    got = vae.decode(z.cuda())[0]
+    w32 = {k: v.float().cuda() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = vae_ref.vae_decode(cfg, w32, z.float().cuda())
+    assert got.shape == (B, 3, 8 * h, 8 * w) and torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < TOL, rel_l2(got, ref)
+    img = got.clamp(-1, 1)
+    enc = vae.encode_moments(img)
+    with torch.no_grad():
+        ref_m = vae_ref.vae_encode_moments(cfg, w32, img.float())
+    assert rel_l2(enc[:, :4], ref_m[:, :4]) < TOL
+    assert torch.equal(got, vae.decode(z.cuda())[0])
