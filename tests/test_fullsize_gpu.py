@@ -458,3 +458,22 @@ def test_sd15_vae_odd_batches_and_non_square_maps(engine_lib, B, h, w):
         ref_m = vae_ref.vae_encode_moments(cfg, w32, img.float())
     assert rel_l2(enc[:, :4], ref_m[:, :4]) < TOL
     assert torch.equal(got, vae.decode(z.cuda())[0])
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 40, 24), (1, 64, 96)])
+def test_sdxl_unet_odd_batches_and_non_square_maps(engine_lib, B, H, W):
+    """SDXL-base UNet (text_time conditioning, d = 64 heads, two / ten transformer layers per block) off the benchmark's
+    shape: odd batch on 40 x 24 latents, batch 1 on 64 x 96 (512 x 768 px)."""
+    cfg = config.sdxl_unet()
+    sd = weights.synth_state_dict(weights.unet_manifest(cfg), seed=45, dtype=torch.float16, perturb=0.1)
+    net = HipUNet2DConditionModel(cfg).load_state_dict(sd)
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, 4, H, W, generator=g).half()
+    ehs = torch.randn(B, 77, 2048, generator=g).half()
+    added = {"text_embeds": torch.randn(B, 1280, generator=g).half(),
+             "time_ids": torch.tensor([[8.0 * H, 8.0 * W, 0, 0, 8.0 * H, 8.0 * W]] * B)}
+    t = torch.tensor(333.0)
+    got = net(x.cuda(), t, ehs.cuda(), added_cond_kwargs={k: v.cuda() for k, v in added.items()})[0]
+    ref = oracle_unet_on_gpu(cfg, sd, x, t, ehs, added)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < TOL, rel_l2(got, ref)
